@@ -1,0 +1,271 @@
+"""Generate tests/golden/*.npz|json by RUNNING THE REFERENCE in this container.
+
+Usage (build container only; the GPU box never runs this):
+    python tests/golden/make_golden.py [--ref /root/reference]
+
+The reference is imported from its checkout (never copied).  Packages it imports
+that are absent here (loguru, pytorch_lightning, torchvision) are replaced by
+empty stand-in modules fabricated in a temp dir -- they carry no reference code.
+Everything written is data: inputs and the reference's outputs.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+
+
+def _stubs(d):
+    os.makedirs(os.path.join(d, "loguru"))
+    open(os.path.join(d, "loguru", "__init__.py"), "w").write(
+        "class _L:\n    def __getattr__(s, n):\n        return lambda *a, **k: None\nlogger = _L()\n")
+    os.makedirs(os.path.join(d, "pytorch_lightning"))
+    open(os.path.join(d, "pytorch_lightning", "__init__.py"), "w").write(
+        "import torch.nn as nn\nclass LightningModule(nn.Module):\n    @property\n    def device(self):\n"
+        "        return next(self.parameters()).device\n")
+    for sub in ("", "transforms", "models"):
+        os.makedirs(os.path.join(d, "torchvision", sub), exist_ok=True)
+    open(os.path.join(d, "torchvision", "__init__.py"), "w").write("")
+    open(os.path.join(d, "torchvision", "models", "__init__.py"), "w").write("")
+    open(os.path.join(d, "torchvision", "transforms", "__init__.py"), "w").write(
+        "class PILToTensor:\n    pass\nfrom . import functional\n")
+    open(os.path.join(d, "torchvision", "transforms", "functional.py"), "w").write("")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    args = ap.parse_args()
+    tmp = tempfile.mkdtemp(prefix="wmar_stubs_")
+    _stubs(tmp)
+    sys.path[:0] = [tmp, args.ref, REPO]
+    os.chdir(args.ref)
+
+    import torch
+    from deps.taming.modules.diffusionmodules.model import Decoder, Encoder
+    from deps.taming.modules.transformer.mingpt import GPT, sample_with_past
+    from deps.taming.modules.vqvae.quantize import VectorQuantizer2
+    from wmar.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
+    from scipy import special
+
+    from wmar_amd.utils import synth
+
+    torch.set_num_threads(8)
+    out = {}
+
+    def ids_file(name):
+        ids = []
+        for line in open(os.path.join(args.ref, "assets", name)):
+            ids.extend(int(t) for t in line.split(","))
+        return ids
+
+    def vq_dict(alive, vocab):
+        # armm_wrapper.py:42-55: dead = list(set(range(V)) - set(alive))
+        dead = list(set(range(vocab)) - set(alive))
+        return {"alive_ids": torch.tensor(alive, dtype=torch.long), "dead_ids": torch.tensor(dead, dtype=torch.long),
+                "embedding": torch.zeros(vocab, 4)}, dead
+
+    # ---------------------------------------------------------------- 1. key KATs
+    kat = {"randperm": [], "keys": {}}
+    for n, seed in [(971, 0), (15413, 12345), (57344, 7), (1, 3), (2, 3), (16384, 2**32 + 5), (1024, 15485863 * 77)]:
+        g = torch.Generator().manual_seed(seed)
+        p = torch.randperm(n, generator=g)
+        kat["randperm"].append({"n": n, "seed": seed, "first": p[:8].tolist(), "last": p[-4:].tolist(),
+                                "sha256": hashlib.sha256(p.numpy().astype("<i8").tobytes()).hexdigest()})
+    key_cfgs = {
+        "taming": dict(alive="vqgan_alive_ids.txt", vocab=16384, seed="linear", split="stratifiedrand", h=1, gamma=0.25),
+        "taming_rand": dict(alive="vqgan_alive_ids.txt", vocab=16384, seed="linear", split="rand", h=1, gamma=0.25),
+        "taming_h2_g50": dict(alive="vqgan_alive_ids.txt", vocab=16384, seed="linear", split="stratifiedrand", h=2, gamma=0.5),
+        "rar": dict(alive="rar_all_ids.txt", vocab=1024, seed="linear", split="stratifiedrand", h=1, gamma=0.25),
+        "chameleon_fixed": dict(alive="chameleon_all_ids.txt", vocab=65536, seed="fixed", split="stratifiedrand", h=0, gamma=0.25),
+    }
+    wms = {}
+    for name, c in key_cfgs.items():
+        alive = ids_file(c["alive"])
+        vq, dead = vq_dict(alive, c["vocab"])
+        wm = GentimeWatermark(vq, c["vocab"], SeedStrategy(c["seed"]), SplitStrategy(c["split"]), c["h"], 2.0, c["gamma"])
+        wms[name] = wm
+        entry = dict(c)
+        entry["dead_sha256"] = hashlib.sha256(np.array(dead, dtype="<i8").tobytes()).hexdigest()
+        entry["dead_is_ascending"] = bool(dead == sorted(dead))
+        entry["str"] = str(wm)
+        ctxs = [[0] * c["h"], [5] * c["h"], [c["vocab"] - 1] * c["h"], [999] + [3] * (c["h"] - 1) if c["h"] else []]
+        entry["contexts"] = []
+        for ctx in ctxs:
+            gl = wm._get_greenlist_ids_for_context(torch.tensor(ctx, dtype=torch.long))
+            entry["contexts"].append({"ctx": ctx, "len": len(gl), "first": gl[:8].tolist(), "last": gl[-6:].tolist(),
+                                      "sha256": hashlib.sha256(gl.numpy().astype("<i8").tobytes()).hexdigest()})
+        if c["seed"] != "fixed":
+            h = hashlib.sha256()
+            for s in range(16):
+                gl = wm._get_greenlist_ids_for_context(torch.tensor([s] + [0] * (c["h"] - 1), dtype=torch.long))
+                h.update(np.sort(gl.numpy()).astype("<i4").tobytes())
+            entry["sha256_sorted_ctx0_15"] = h.hexdigest()
+        kat["keys"][name] = entry
+    kat["betainc"] = [{"a": a, "b": b, "x": x, "v": float(special.betainc(a, b, x))}
+                      for a, b, x in [(0, 256, .25), (1, 255, .25), (64, 192, .25), (100, 156, .25), (255, 1, .25),
+                                      (30, 226, .25), (128, 128, .5), (200, 56, .5), (1, 1, .25), (3, 1021, .1),
+                                      (500, 524, .25), (250, 6, 0.25), (70, 186, 0.25)]]
+    json.dump(kat, open(os.path.join(HERE, "key_kat.json"), "w"), indent=1)
+
+    # ------------------------------------------------------- 2. logit processor (A4)
+    rs = np.random.RandomState(1234)
+    wm = wms["taming"]
+    past = torch.from_numpy(rs.randint(0, 16384, size=(4, 5)).astype(np.int64))
+    past[0, -1] = 7  # a class-id-like context
+    logits = torch.from_numpy(rs.randn(4, 16384).astype(np.float32))
+    proc = wm.spawn_logit_processor()
+    lg_out = proc(past_ids=past, logits=logits.clone())
+    out["proc_taming_past"] = past.numpy()
+    out["proc_taming_logits"] = logits.numpy()
+    out["proc_taming_changed_sha256"] = np.frombuffer(hashlib.sha256(
+        np.ascontiguousarray((lg_out != logits).numpy()).tobytes()).digest(), dtype=np.uint8)
+    out["proc_taming_out"] = lg_out.numpy()
+    # h=2: a row with t < h is skipped (ValueError swallowed)
+    wm2 = wms["taming_h2_g50"]
+    wm2.delta = 1.5
+    past2 = torch.from_numpy(rs.randint(0, 16384, size=(2, 1)).astype(np.int64))
+    out["proc_h2_short_out"] = wm2.spawn_logit_processor()(past_ids=past2, logits=logits[:2].clone()).numpy()
+    out["proc_h2_short_past"] = past2.numpy()
+    past3 = torch.from_numpy(rs.randint(0, 16384, size=(2, 3)).astype(np.int64))
+    out["proc_h2_past"] = past3.numpy()
+    out["proc_h2_out"] = wm2.spawn_logit_processor()(past_ids=past3, logits=logits[:2].clone()).numpy()
+    # spatial h=3 / h=1
+    vq, _ = vq_dict(ids_file("vqgan_alive_ids.txt"), 16384)
+    wms3 = GentimeWatermark(vq, 16384, SeedStrategy.SPATIAL, SplitStrategy.RANDOM_STRATIFIED, 3, 2.0, 0.25, spatial_dim=4)
+    past4 = torch.from_numpy(rs.randint(0, 16384, size=(2, 6)).astype(np.int64))
+    out["proc_sp3_past"] = past4.numpy()
+    out["proc_sp3_out"] = wms3.spawn_logit_processor()(past_ids=past4, logits=logits[:2].clone()).numpy()
+    import contextlib, io
+    wms1 = GentimeWatermark(vq, 16384, SeedStrategy.SPATIAL, SplitStrategy.RANDOM_STRATIFIED, 1, 2.0, 0.25, spatial_dim=4)
+    with contextlib.redirect_stdout(io.StringIO()):
+        past5 = torch.from_numpy(rs.randint(0, 16384, size=(2, 8)).astype(np.int64))   # t % S == 0 -> [-S]
+        out["proc_sp1a_past"] = past5.numpy()
+        out["proc_sp1a_out"] = wms1.spawn_logit_processor()(past_ids=past5, logits=logits[:2].clone()).numpy()
+        past6 = torch.from_numpy(rs.randint(0, 16384, size=(2, 7)).astype(np.int64))   # else [-1]
+        out["proc_sp1b_past"] = past6.numpy()
+        out["proc_sp1b_out"] = wms1.spawn_logit_processor()(past_ids=past6, logits=logits[:2].clone()).numpy()
+
+    # ------------------------------------------- 3. whole sampling loop, small GPT (A5-A8)
+    cfg = synth.GPTConfig(vocab_size=16384, block_size=16, n_layer=2, n_head=4, n_embd=128)
+    sd = synth.synth_gpt_state(cfg, seed=3, logit_scale=40.0, with_mask=True)
+    gpt = GPT(vocab_size=cfg.vocab_size, block_size=cfg.block_size, n_layer=cfg.n_layer, n_head=cfg.n_head,
+              n_embd=cfg.n_embd)
+    gpt.load_state_dict(sd, strict=True)  # pins the checkpoint key layout
+    gpt.eval()
+    wm = wms["taming"]
+    wm.delta = 2.0
+    cond = torch.tensor([[7], [980], [1], [340]], dtype=torch.long)
+    rec = {"logits": [], "q": []}
+    orig_fwd = gpt.forward_with_past
+
+    def spy(idx, **kw):
+        r = orig_fwd(idx, **kw)
+        rec["logits"].append(r[0][:, -1, :].detach().clone().numpy())
+        return r
+
+    gpt.forward_with_past = spy
+    for tag, (tk, tp, T) in {"k250p92": (250, 0.92, 1.0), "k100p80T13": (100, 0.8, 1.3), "nok_p95": (None, 0.95, 0.9),
+                             "k50nop": (50, None, 1.0), "plain": (None, None, 1.0)}.items():
+        rec["logits"].clear()
+        torch.manual_seed(11)
+        toks = sample_with_past(cond, gpt, steps=16, temperature=T, sample_logits=True, top_k=tk, top_p=tp,
+                                logit_processor=wm.spawn_logit_processor())
+        torch.manual_seed(11)  # the noise multinomial drew, step by step
+        q = np.stack([torch.empty(4, 16384).exponential_(1).numpy() for _ in range(16)])
+        out[f"loop_{tag}_tokens"] = toks.numpy()
+        if tag == "k250p92":
+            out["loop_logits"] = np.stack(rec["logits"])[:6]      # [6,4,V] raw model logits (steps 0..5)
+            out["loop_q"] = q[:6]
+    out["loop_cond"] = cond.numpy()
+    # unwatermarked run
+    torch.manual_seed(11)
+    out["loop_nowm_tokens"] = sample_with_past(cond, gpt, steps=16, temperature=1.0, sample_logits=True, top_k=250,
+                                               top_p=0.92, logit_processor=None).numpy()
+    gpt.forward_with_past = orig_fwd
+
+    # GPT step fixture: logits at steps 0..3 for a fixed token sequence (teacher forced)
+    seq = torch.from_numpy(rs.randint(0, 16384, size=(3, 6)).astype(np.int64))
+    past = None
+    lgs = []
+    for t in range(6):
+        lg, _, present = gpt.forward_with_past(seq[:, t:t + 1], past=past, past_length=t)
+        past = [present] if past is None else past + [present]
+        lgs.append(lg[:, -1, :].detach().numpy())
+    out["gpt_seq"] = seq.numpy()
+    out["gpt_logits"] = np.stack(lgs)[:, :, ::16].copy()  # every 16th logit, [6,3,1024]
+    out["gpt_logits_argmax"] = np.stack(lgs).argmax(-1)
+
+    # ------------------------------------------------------------------ 4. detector
+    wm = wms["taming"]
+    torch.manual_seed(123)
+    codes = torch.randint(0, 16384, (2, 256))
+    out["det_codes_rand"] = codes.numpy()
+    out["det_pvals_rand"] = wm.detect(codes).numpy()
+    gen_codes = torch.from_numpy(out["loop_k250p92_tokens"])  # 16 watermarked tokens per row
+    pv, masks = wm.detect(gen_codes, return_masks=True)
+    out["det_pvals_gen"] = pv.numpy()
+    out["det_masks_gen"] = np.array(masks, dtype=np.int8)
+    rep = torch.tensor([[5, 9, 5, 9, 5, 9, 5, 9, 11, 5, 9, 3]], dtype=torch.long)  # repeated bigrams
+    pv, masks = wm.detect(rep, return_masks=True)
+    out["det_codes_rep"] = rep.numpy()
+    out["det_pvals_rep"] = pv.numpy()
+    out["det_masks_rep"] = np.array(masks, dtype=np.int8)
+    pv, masks = wms["taming_h2_g50"].detect(codes[:, :40], return_masks=True)
+    out["det_pvals_h2"] = pv.numpy()
+    out["det_masks_h2"] = np.array(masks, dtype=np.int8)
+    out["det_pvals_rar"] = wms["rar"].detect((torch.arange(256) % 1024).view(1, -1)).numpy()
+    cham_codes = torch.from_numpy(rs.randint(0, 65536, size=(1, 64)).astype(np.int64))
+    out["det_codes_cham"] = cham_codes.numpy()
+    out["det_pvals_cham"] = wms["chameleon_fixed"].detect(cham_codes).numpy()
+    sp_codes = torch.from_numpy(rs.randint(0, 16384, size=(2, 16)).astype(np.int64))
+    out["det_codes_sp"] = sp_codes.numpy()
+    pv, masks = wms3.detect(sp_codes, return_masks=True)
+    out["det_pvals_sp3"] = pv.numpy()
+    out["det_masks_sp3"] = np.array(masks, dtype=np.int8)
+    pv, masks = wms1.detect(sp_codes, return_masks=True)
+    out["det_pvals_sp1"] = pv.numpy()
+    out["det_masks_sp1"] = np.array(masks, dtype=np.int8)
+
+    # -------------------------------------------------------------------- 5. VQGAN
+    vcfg = synth.VQConfig(ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(8,), resolution=32,
+                          z_channels=16, embed_dim=8, n_embed=512)
+    vsd = synth.synth_vq_state(vcfg, seed=5)
+    dd = dict(double_z=False, z_channels=vcfg.z_channels, resolution=vcfg.resolution, in_channels=3, out_ch=3,
+              ch=vcfg.ch, ch_mult=list(vcfg.ch_mult), num_res_blocks=vcfg.num_res_blocks,
+              attn_resolutions=list(vcfg.attn_resolutions), dropout=0.0)
+    enc, dec = Encoder(**dd).eval(), Decoder(**dd).eval()
+    enc.load_state_dict({k[len("encoder."):]: v for k, v in vsd.items() if k.startswith("encoder.")}, strict=True)
+    dec.load_state_dict({k[len("decoder."):]: v for k, v in vsd.items() if k.startswith("decoder.")}, strict=True)
+    vq = VectorQuantizer2(vcfg.n_embed, vcfg.embed_dim, beta=0.25).eval()
+    vq.load_state_dict({"embedding.weight": vsd["quantize.embedding.weight"]}, strict=True)
+    qc = torch.nn.Conv2d(vcfg.z_channels, vcfg.embed_dim, 1)
+    pqc = torch.nn.Conv2d(vcfg.embed_dim, vcfg.z_channels, 1)
+    qc.load_state_dict({"weight": vsd["quant_conv.weight"], "bias": vsd["quant_conv.bias"]})
+    pqc.load_state_dict({"weight": vsd["post_quant_conv.weight"], "bias": vsd["post_quant_conv.bias"]})
+    S = vcfg.codes_size
+    vcodes = torch.from_numpy(rs.randint(0, vcfg.n_embed, size=(2, S * S)).astype(np.int64))
+    with torch.no_grad():
+        zq = vq.get_codebook_entry(vcodes.reshape(-1), shape=(2, S, S, vcfg.embed_dim))
+        img = dec(pqc(zq)).clamp(-1, 1)
+        h = qc(enc(img))
+        _, _, info = vq(h)
+        codes2 = info[2].view(2, -1)
+    out["vq_codes"] = vcodes.numpy()
+    out["vq_images"] = img.numpy()
+    out["vq_prequant"] = h.permute(0, 2, 3, 1).reshape(-1, vcfg.embed_dim).numpy()
+    out["vq_codes_roundtrip"] = codes2.numpy()
+
+    np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
+    sz = os.path.getsize(os.path.join(HERE, "reference_vectors.npz"))
+    print("wrote reference_vectors.npz", sz, "bytes; key_kat.json")
+
+
+if __name__ == "__main__":
+    main()

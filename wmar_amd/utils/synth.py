@@ -1,0 +1,268 @@
+"""Model configs and synthetic (seeded, random-init) checkpoints in the reference's layout.
+
+There is no network and no pretrained checkpoint on the GPU box, so benchmarks and
+parity tests run on random-init weights of the real architectures.  The tensors
+carry exactly the key names and shapes of the reference's Lightning checkpoint
+(``net2net.ckpt["state_dict"]``; reference modules:
+deps/taming/modules/transformer/mingpt.py:125-146 (GPT),
+deps/taming/modules/diffusionmodules/model.py:343-538 (Encoder / Decoder),
+deps/taming/models/vqgan.py:30-38 (quantize / quant_conv / post_quant_conv)),
+which tests/golden/make_golden.py pins with ``load_state_dict(strict=True)``
+against the reference module trees.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Dict, List, Tuple
+
+import torch
+
+
+@dataclasses.dataclass
+class GPTConfig:
+    vocab_size: int = 16384
+    block_size: int = 256
+    n_layer: int = 48
+    n_head: int = 24
+    n_embd: int = 1536
+
+    @property
+    def head_dim(self) -> int:
+        return self.n_embd // self.n_head
+
+
+@dataclasses.dataclass
+class VQConfig:
+    ch: int = 128
+    ch_mult: Tuple[int, ...] = (1, 1, 2, 2, 4)
+    num_res_blocks: int = 2
+    attn_resolutions: Tuple[int, ...] = (16,)
+    resolution: int = 256
+    in_channels: int = 3
+    out_ch: int = 3
+    z_channels: int = 256
+    embed_dim: int = 256
+    n_embed: int = 16384
+
+    @property
+    def num_resolutions(self) -> int:
+        return len(self.ch_mult)
+
+    @property
+    def codes_size(self) -> int:
+        return self.resolution // (2 ** (self.num_resolutions - 1))
+
+
+TAMING_GPT = GPTConfig()
+TAMING_VQ = VQConfig()
+
+
+def gpt_shapes(cfg: GPTConfig, with_mask: bool = False) -> Dict[str, Tuple[int, ...]]:
+    d, v = cfg.n_embd, cfg.vocab_size
+    s: Dict[str, Tuple[int, ...]] = {"tok_emb.weight": (v, d), "pos_emb": (1, cfg.block_size, d)}
+    for i in range(cfg.n_layer):
+        p = f"blocks.{i}."
+        for ln in ("ln1", "ln2"):
+            s[p + ln + ".weight"] = (d,)
+            s[p + ln + ".bias"] = (d,)
+        for lin in ("key", "query", "value", "proj"):
+            s[p + f"attn.{lin}.weight"] = (d, d)
+            s[p + f"attn.{lin}.bias"] = (d,)
+        if with_mask:
+            s[p + "attn.mask"] = (1, 1, cfg.block_size, cfg.block_size)
+        s[p + "mlp.0.weight"] = (4 * d, d)
+        s[p + "mlp.0.bias"] = (4 * d,)
+        s[p + "mlp.2.weight"] = (d, 4 * d)
+        s[p + "mlp.2.bias"] = (d,)
+    s["ln_f.weight"] = (d,)
+    s["ln_f.bias"] = (d,)
+    s["head.weight"] = (v, d)
+    return s
+
+
+def _res(s, p, cin, cout):
+    s[p + "norm1.weight"] = (cin,)
+    s[p + "norm1.bias"] = (cin,)
+    s[p + "conv1.weight"] = (cout, cin, 3, 3)
+    s[p + "conv1.bias"] = (cout,)
+    s[p + "norm2.weight"] = (cout,)
+    s[p + "norm2.bias"] = (cout,)
+    s[p + "conv2.weight"] = (cout, cout, 3, 3)
+    s[p + "conv2.bias"] = (cout,)
+    if cin != cout:
+        s[p + "nin_shortcut.weight"] = (cout, cin, 1, 1)
+        s[p + "nin_shortcut.bias"] = (cout,)
+
+
+def _attn(s, p, c):
+    s[p + "norm.weight"] = (c,)
+    s[p + "norm.bias"] = (c,)
+    for n in ("q", "k", "v", "proj_out"):
+        s[p + n + ".weight"] = (c, c, 1, 1)
+        s[p + n + ".bias"] = (c,)
+
+
+def encoder_shapes(cfg: VQConfig) -> Dict[str, Tuple[int, ...]]:
+    s: Dict[str, Tuple[int, ...]] = {}
+    s["conv_in.weight"] = (cfg.ch, cfg.in_channels, 3, 3)
+    s["conv_in.bias"] = (cfg.ch,)
+    in_mult = (1,) + tuple(cfg.ch_mult)
+    res = cfg.resolution
+    block_in = cfg.ch
+    for lvl in range(cfg.num_resolutions):
+        block_in = cfg.ch * in_mult[lvl]
+        block_out = cfg.ch * cfg.ch_mult[lvl]
+        for b in range(cfg.num_res_blocks):
+            _res(s, f"down.{lvl}.block.{b}.", block_in, block_out)
+            block_in = block_out
+            if res in cfg.attn_resolutions:
+                _attn(s, f"down.{lvl}.attn.{b}.", block_in)
+        if lvl != cfg.num_resolutions - 1:
+            s[f"down.{lvl}.downsample.conv.weight"] = (block_in, block_in, 3, 3)
+            s[f"down.{lvl}.downsample.conv.bias"] = (block_in,)
+            res //= 2
+    _res(s, "mid.block_1.", block_in, block_in)
+    _attn(s, "mid.attn_1.", block_in)
+    _res(s, "mid.block_2.", block_in, block_in)
+    s["norm_out.weight"] = (block_in,)
+    s["norm_out.bias"] = (block_in,)
+    s["conv_out.weight"] = (cfg.z_channels, block_in, 3, 3)
+    s["conv_out.bias"] = (cfg.z_channels,)
+    return s
+
+
+def decoder_shapes(cfg: VQConfig) -> Dict[str, Tuple[int, ...]]:
+    s: Dict[str, Tuple[int, ...]] = {}
+    block_in = cfg.ch * cfg.ch_mult[-1]
+    res = cfg.resolution // 2 ** (cfg.num_resolutions - 1)
+    s["conv_in.weight"] = (block_in, cfg.z_channels, 3, 3)
+    s["conv_in.bias"] = (block_in,)
+    _res(s, "mid.block_1.", block_in, block_in)
+    _attn(s, "mid.attn_1.", block_in)
+    _res(s, "mid.block_2.", block_in, block_in)
+    for lvl in reversed(range(cfg.num_resolutions)):
+        block_out = cfg.ch * cfg.ch_mult[lvl]
+        for b in range(cfg.num_res_blocks + 1):
+            _res(s, f"up.{lvl}.block.{b}.", block_in, block_out)
+            block_in = block_out
+            if res in cfg.attn_resolutions:
+                _attn(s, f"up.{lvl}.attn.{b}.", block_in)
+        if lvl != 0:
+            s[f"up.{lvl}.upsample.conv.weight"] = (block_in, block_in, 3, 3)
+            s[f"up.{lvl}.upsample.conv.bias"] = (block_in,)
+            res *= 2
+    s["norm_out.weight"] = (block_in,)
+    s["norm_out.bias"] = (block_in,)
+    s["conv_out.weight"] = (cfg.out_ch, block_in, 3, 3)
+    s["conv_out.bias"] = (cfg.out_ch,)
+    return s
+
+
+def vq_shapes(cfg: VQConfig) -> Dict[str, Tuple[int, ...]]:
+    s: Dict[str, Tuple[int, ...]] = {}
+    for k, v in encoder_shapes(cfg).items():
+        s["encoder." + k] = v
+    for k, v in decoder_shapes(cfg).items():
+        s["decoder." + k] = v
+    s["quantize.embedding.weight"] = (cfg.n_embed, cfg.embed_dim)
+    s["quant_conv.weight"] = (cfg.embed_dim, cfg.z_channels, 1, 1)
+    s["quant_conv.bias"] = (cfg.embed_dim,)
+    s["post_quant_conv.weight"] = (cfg.z_channels, cfg.embed_dim, 1, 1)
+    s["post_quant_conv.bias"] = (cfg.z_channels,)
+    return s
+
+
+def _fill(shapes, gen: torch.Generator, device, kind: str, logit_scale: float = 1.0):
+    """Seeded init.  `kind` picks the distribution family per tensor role."""
+    out = {}
+    for k, shp in shapes.items():
+        leaf = k.rsplit(".", 1)[-1]
+        is_norm = any(t in k for t in ("ln1.", "ln2.", "ln_f.", "norm")) and leaf in ("weight", "bias")
+        if k.endswith("attn.mask"):
+            n = shp[-1]
+            t = torch.tril(torch.ones(n, n)).view(shp)
+        elif is_norm:
+            t = torch.randn(shp, generator=gen) * 0.1
+            if leaf == "weight":
+                t = t + 1.0
+        elif leaf == "bias":
+            t = torch.randn(shp, generator=gen) * 0.02
+        elif k == "pos_emb":
+            t = torch.randn(shp, generator=gen) * 0.02
+        elif kind == "gpt":
+            t = torch.randn(shp, generator=gen) * 0.02
+            if k == "head.weight":
+                t = t * logit_scale
+        elif k == "quantize.embedding.weight":
+            t = torch.rand(shp, generator=gen) * 2.0 - 1.0
+        else:  # conv weights: kaiming-uniform-like fan-in scaling
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            bound = (3.0 / fan_in) ** 0.5
+            t = (torch.rand(shp, generator=gen) * 2.0 - 1.0) * bound
+        out[k] = t.to(torch.float32).to(device)
+    return out
+
+
+def synth_gpt_state(cfg: GPTConfig, seed: int = 0, device="cpu", logit_scale: float = 1.0,
+                    with_mask: bool = False) -> Dict[str, torch.Tensor]:
+    """Random-init GPT tensors keyed like ``transformer.*`` minus the prefix.
+
+    ``logit_scale`` multiplies ``head.weight`` so that logits are not flat (flat logits make
+    the watermark saturate: every sampled token green)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    return _fill(gpt_shapes(cfg, with_mask), g, device, "gpt", logit_scale)
+
+
+def synth_vq_state(cfg: VQConfig, seed: int = 0, device="cpu") -> Dict[str, torch.Tensor]:
+    """Random-init VQGAN tensors keyed like ``first_stage_model.*`` minus the prefix."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed + 7919)
+    return _fill(vq_shapes(cfg), g, device, "vq")
+
+
+def synth_gpt_state_fast(cfg: GPTConfig, seed: int = 0, device="cuda", logit_scale: float = 1.0):
+    """Same layout, drawn on `device` directly (full-size benchmark weights: 1.4 G params)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = {}
+    for k, shp in gpt_shapes(cfg).items():
+        leaf = k.rsplit(".", 1)[-1]
+        is_norm = any(t in k for t in ("ln1.", "ln2.", "ln_f."))
+        if is_norm:
+            t = torch.randn(shp, generator=g, device=device) * 0.1
+            if leaf == "weight":
+                t += 1.0
+        elif leaf == "bias":
+            t = torch.randn(shp, generator=g, device=device) * 0.02
+        else:
+            t = torch.randn(shp, generator=g, device=device) * 0.02
+            if k == "head.weight":
+                t *= logit_scale
+        out[k] = t
+    return out
+
+
+def synth_vq_state_fast(cfg: VQConfig, seed: int = 0, device="cuda"):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed + 7919)
+    out = {}
+    for k, shp in vq_shapes(cfg).items():
+        leaf = k.rsplit(".", 1)[-1]
+        if "norm" in k:
+            t = torch.randn(shp, generator=g, device=device) * 0.1
+            if leaf == "weight":
+                t += 1.0
+        elif leaf == "bias":
+            t = torch.randn(shp, generator=g, device=device) * 0.02
+        elif k == "quantize.embedding.weight":
+            t = torch.rand(shp, generator=g, device=device) * 2.0 - 1.0
+        else:
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            t = (torch.rand(shp, generator=g, device=device) * 2.0 - 1.0) * (3.0 / fan_in) ** 0.5
+        out[k] = t
+    return out
