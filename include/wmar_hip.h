@@ -1,0 +1,186 @@
+/*
+ * wmar_hip.h -- C ABI of libwmar_hip.so, the MI355X (gfx950) implementation of
+ * wmar's watermarked autoregressive image generation + detection hot path.
+ *
+ * Conventions
+ *   - plain C types only; every `*_dev` / "device" pointer is a HIP device pointer
+ *     (e.g. torch.Tensor.data_ptr()); `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream).  Tensors stay owned by the caller.
+ *   - every function returns 0 on success or a negative WMAR_E* code;
+ *     wmar_last_error() returns a human-readable message for the calling thread.
+ *   - nothing here allocates after the corresponding *_create call.
+ *
+ * Each entry point cites the reference interface (facebookresearch/wmar) it replaces.
+ */
+#ifndef WMAR_HIP_H
+#define WMAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WMAR_OK 0
+#define WMAR_EINVAL (-1)   /* bad argument / unsupported shape            */
+#define WMAR_EHIP (-2)     /* HIP runtime error                           */
+#define WMAR_ESHORT (-3)   /* detect: len(codes) - context_size < 1       */
+#define WMAR_ENOMEM (-4)
+#define WMAR_EMISSING (-5) /* a required checkpoint tensor is missing      */
+
+/* enum values of wmar.watermarking.gentime_watermark.SeedStrategy / SplitStrategy (:95-106) */
+#define WMAR_SEED_FIXED 0
+#define WMAR_SEED_LINEAR 1
+#define WMAR_SEED_SPATIAL 2
+#define WMAR_SPLIT_RAND 0
+#define WMAR_SPLIT_STRATIFIED 1
+
+const char* wmar_last_error(void);
+int wmar_version(void);
+
+/* ---------------------------------------------------------------- watermark key
+ * The greenlist of a context is a pure function of seed32 = (salt*sum(ctx)) mod 2^32
+ * (GentimeWatermark._get_greenlist_ids_for_context, gentime_watermark.py:219-226, and
+ * _split_with_seed :161-174).  The whole key is therefore a table of bitmaps:
+ * row r = greenlist of context sum r, `vocab` bits packed LSB-first into uint32
+ * words, row stride = wmar_key_row_words(vocab). */
+typedef struct wmar_key_params {
+    uint64_t salt_key;        /* GentimeWatermark.salt_key (default 15485863)            */
+    const int64_t* alive_ids; /* host, in the order init_alivecodes produced them        */
+    int64_t n_alive;
+    const int64_t* dead_ids;  /* host                                                    */
+    int64_t n_dead;
+    int64_t vocab_size;
+    double gamma;
+    int32_t split_strategy;   /* WMAR_SPLIT_*  (clustering is out of scope)              */
+    int32_t seed_strategy;    /* WMAR_SEED_*                                             */
+} wmar_key_params;
+
+int64_t wmar_key_row_words(int64_t vocab_size);
+/* Number of table rows needed so that every reachable context sum has a row:
+ * FIXED -> 1; LINEAR / SPATIAL with context size h and token ids < max_token -> h*(max_token-1)+1. */
+int64_t wmar_key_table_rows(int32_t seed_strategy, int32_t context_size, int64_t max_token);
+/* Host builder (MT19937 + Fisher-Yates, `n_threads` host threads; 0 = all cores).
+ * Writes rows [row0, row0+n_rows) to `out_host`.  Replaces the per-row, per-step
+ * _split_with_seed calls of gentime_watermark.py:266 and :281. */
+int wmar_key_table_build(const wmar_key_params* key, int64_t row0, int64_t n_rows, uint32_t* out_host,
+                         int32_t n_threads);
+/* One greenlist in the reference's order (ids as _split_with_seed returns them). Host. */
+int64_t wmar_key_greenlist(const wmar_key_params* key, uint64_t seed, int64_t* out_ids_host);
+
+/* What every device-side watermark call needs to find a row's bitmap. */
+typedef struct wmar_wm_ctx {
+    const uint32_t* table_dev; /* [n_rows, row_words]                                     */
+    int64_t n_rows;
+    int64_t vocab_size;
+    int32_t seed_strategy;
+    int32_t context_size;      /* h                                                       */
+    int32_t spatial_dim;       /* 16 Taming/RAR, 32 Chameleon (gentime_watermark.py:153)  */
+    float delta;
+} wmar_wm_ctx;
+
+/* GentimeWatermark._process_logits (gentime_watermark.py:229-271): logits[b, G(ctx_b)] += delta,
+ * in place.  past_ids_dev: int64 [B, t] with row stride `past_stride`.  Rows whose context is
+ * too short are left untouched (the reference swallows the ValueError). */
+int wmar_wm_process_logits(const wmar_wm_ctx* wm, float* logits_dev, int64_t B, const int64_t* past_ids_dev,
+                           int64_t t, int64_t past_stride, void* stream);
+
+/* The sampling stage of sample_with_past (mingpt.py:348-363) fused into one kernel per row:
+ * watermark bias -> /temperature -> top-k -> top-p -> softmax -> argmax(p / q).
+ * wm == NULL: no watermark.  top_k <= 0: off.  top_p < 0: off.  q_dev: the Exp(1) noise
+ * torch.multinomial would draw, [B, V].  scratch_dev: float [B, V].  tok_out_dev: int64 [B].
+ * The arithmetic is the one pinned in include/wmar_math.h. */
+int wmar_sample_fused(const wmar_wm_ctx* wm, const float* logits_dev, int64_t B, int64_t V,
+                      const int64_t* past_ids_dev, int64_t t, int64_t past_stride, float temperature,
+                      int32_t top_k, double top_p, const float* q_dev, float* scratch_dev,
+                      int64_t* tok_out_dev, void* stream);
+
+/* GentimeWatermark.detect (gentime_watermark.py:285-344): per row of codes_dev int64 [B, L]:
+ * unique (h+1)-grams -> n_scored, n_green -> p = I_gamma(n_green, 1+n_scored-n_green) in fp64
+ * (NaN when n_green == 0, as scipy.special.betainc).  mask_dev (nullable): int8 [B, mask_stride],
+ * entry i: -1 for the first h positions and for repeated n-grams, else the green bit.
+ * Returns WMAR_ESHORT when L - h < 1 (the reference raises ValueError). */
+int wmar_detect(const wmar_wm_ctx* wm, double gamma, const int64_t* codes_dev, int64_t B, int64_t L,
+                int32_t* n_scored_dev, int32_t* n_green_dev, double* pval_dev, int8_t* mask_dev,
+                int64_t mask_stride, void* stream);
+/* number of n-grams the detector enumerates for a passage of length L (mask length = h + this) */
+int64_t wmar_detect_num_ngrams(int32_t seed_strategy, int32_t context_size, int64_t L);
+
+/* ------------------------------------------------------------------------ GPT
+ * minGPT decoder with a static KV cache (deps/taming/modules/transformer/mingpt.py:125-214).
+ * Tensors are looked up by their checkpoint key names relative to `transformer.`
+ * (tok_emb.weight, pos_emb, blocks.N.{ln1,ln2}.{weight,bias}, blocks.N.attn.{key,query,value,proj}.{weight,bias},
+ *  blocks.N.mlp.{0,2}.{weight,bias}, ln_f.{weight,bias}, head.weight), all fp32 device pointers in
+ * torch's nn.Linear layout; they are repacked into MFMA-fragment order at create time and
+ * need not outlive the call. */
+typedef struct wmar_gpt_config {
+    int32_t vocab_size, block_size, n_layer, n_head, n_embd;
+    int32_t max_batch; /* KV cache and workspaces are sized for this */
+} wmar_gpt_config;
+
+typedef struct wmar_gpt wmar_gpt;
+
+int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const void* const* tensors_dev,
+                    int32_t n_tensors, void* stream, wmar_gpt** out);
+void wmar_gpt_destroy(wmar_gpt* g);
+int64_t wmar_gpt_device_bytes(const wmar_gpt* g);
+
+/* GPT.forward_with_past for one new token per sequence (mingpt.py:183-214): consumes
+ * tok_dev int64 [B] at position `pos` (= past_length), appends K/V at `pos`, writes
+ * logits_dev float [B, vocab].  Positions must be fed in order 0,1,2,... */
+int wmar_gpt_decode_step(wmar_gpt* g, const int64_t* tok_dev, int64_t B, int32_t pos, float* logits_dev,
+                         void* stream);
+
+/* sample_with_past (mingpt.py:326-368) as `steps` replays of ONE captured hipGraph
+ * (decode step + fused watermark/sampling + position advance; the position lives in
+ * device memory).  cond_dev int64 [B] (the class token), q_dev float [steps, B, V] (noise for
+ * every step, see wmar_sample_fused), tokens_out_dev int64 [B, steps].
+ * logits_trace_dev (nullable): float [steps, B, V], raw model logits per step. */
+typedef struct wmar_sample_params {
+    float temperature;
+    int32_t top_k;  /* <= 0: off */
+    double top_p;   /* < 0: off  */
+    int32_t use_graph; /* 1: hipGraph replay, 0: eager launches */
+} wmar_sample_params;
+
+int wmar_gpt_generate(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_params* sp, const int64_t* cond_dev,
+                      int64_t B, int32_t steps, const float* q_dev, int64_t* tokens_out_dev,
+                      float* logits_trace_dev, void* stream);
+
+/* per-kernel-class device time of the last wmar_gpt_generate with timing enabled (ms):
+ * [0]=gemm [1]=attention [2]=residual/LN [3]=sampler [4]=total step avg.  Debug aid for bench.py. */
+int wmar_gpt_set_timing(wmar_gpt* g, int32_t enabled);
+int wmar_gpt_get_timing(wmar_gpt* g, double* out5);
+
+/* ---------------------------------------------------------------------- VQGAN
+ * Taming VQGAN (deps/taming/models/vqgan.py:30-73, modules/diffusionmodules/model.py:343-538,
+ * modules/vqvae/quantize.py:272-331).  Tensors by key name relative to `first_stage_model.`
+ * (encoder.*, decoder.*, quantize.embedding.weight, quant_conv.*, post_quant_conv.*). */
+typedef struct wmar_vq_config {
+    int32_t ch, num_res_blocks, resolution, in_channels, out_ch, z_channels, embed_dim, n_embed;
+    int32_t n_levels;
+    int32_t ch_mult[8];
+    int32_t n_attn_res;
+    int32_t attn_resolutions[8];
+    int32_t max_batch;
+} wmar_vq_config;
+
+typedef struct wmar_vq wmar_vq;
+
+int wmar_vq_create(const wmar_vq_config* cfg, const char* const* names, const void* const* tensors_dev,
+                   int32_t n_tensors, void* stream, wmar_vq** out);
+void wmar_vq_destroy(wmar_vq* v);
+int64_t wmar_vq_device_bytes(const wmar_vq* v);
+
+/* TamingARMMWrapper.codes_to_images (wmar/models/taming_wrapper.py:79-84): codes int64 [B, S*S]
+ * -> images float [B, 3, R, R] (NCHW) clamped to [-1, 1]. */
+int wmar_vq_decode(wmar_vq* v, const int64_t* codes_dev, int64_t B, float* images_dev, void* stream);
+/* TamingARMMWrapper.images_to_codes (taming_wrapper.py:88-92): images float [B, 3, R, R] -> codes int64 [B, S*S].
+ * prequant_dev (nullable): float [B*S*S, embed_dim], the vectors handed to the quantizer. */
+int wmar_vq_encode(wmar_vq* v, const float* images_dev, int64_t B, int64_t* codes_dev, float* prequant_dev,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WMAR_HIP_H */

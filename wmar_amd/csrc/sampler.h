@@ -1,0 +1,56 @@
+// Argument blocks shared by watermark.hip (kernels) and gpt.hip (generation graph).
+#pragma once
+#include "common.h"
+
+namespace wmar {
+
+struct WmDev {
+    const uint32_t* table;
+    long long n_rows;
+    long long row_words;
+    int seed_mode, h, S;
+    float delta;
+    int enabled;
+};
+
+inline WmDev make_wm(const wmar_wm_ctx* wm) {
+    WmDev d{};
+    if (wm) {
+        d.table = wm->table_dev;
+        d.n_rows = wm->n_rows;
+        d.row_words = (wm->vocab_size + 31) / 32;
+        d.seed_mode = wm->seed_strategy;
+        d.h = wm->context_size;
+        d.S = wm->spatial_dim;
+        d.delta = wm->delta;
+        d.enabled = 1;
+    }
+    return d;
+}
+
+struct SampArgs {
+    WmDev wm;
+    const float* logits;
+    long long V;
+    const long long* past;       // [B, past_stride]
+    long long past_stride;
+    long long t_host;            // used when t_dev == nullptr
+    const int* t_dev;            // device-resident current length (generation graph)
+    float temperature;
+    int top_k;
+    int use_top_p;
+    float top_p_thr;             // (float)(1 - top_p)
+    const float* q;              // [B, V]
+    long long q_step_stride;     // elements between steps when q is indexed by *step_dev
+    const int* step_dev;         // nullable
+    float* scratch;              // [B, V]
+    long long* tok_out;          // [B]
+    long long tok_out_stride;    // tok_out[b*stride + step]
+    long long* past_append;      // nullable: past[b*past_stride + t] = token
+    float* trace;                // nullable: raw logits copy [steps][B][V]
+    long long B;
+};
+
+int launch_sample_fused(const SampArgs& a, hipStream_t st);
+
+}  // namespace wmar

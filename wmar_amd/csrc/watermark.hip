@@ -1,0 +1,500 @@
+// Watermark kernels for gfx950: logit bias, fused bias+warp+sample, detector.
+//
+// All three are HBM/latency-bound integer-and-compare work: one workgroup per row,
+// coalesced row reads, order-independent integer reductions (so results do not depend
+// on wave scheduling), LDS histograms for the exact top-k / top-p boundaries.
+// Compile with -ffp-contract=off: the arithmetic is the one pinned in include/wmar_math.h.
+#include "sampler.h"
+#include "../../include/wmar_math.h"
+
+namespace wmar {
+
+__device__ __forceinline__ const uint32_t* wm_row(const WmDev& wm, const long long* past, long long t) {
+    if (!wm.enabled) return nullptr;
+    long long r = ctx_row(past, t, wm.seed_mode, wm.h, wm.S);
+    if (r < 0 || r >= wm.n_rows) return nullptr;
+    return wm.table + r * wm.row_words;
+}
+
+// ------------------------------------------------------------------ logit processor
+__global__ __launch_bounds__(256) void k_wm_bias(WmDev wm, float* logits, long long V, const long long* past,
+                                                 long long t, long long past_stride) {
+    const long long b = blockIdx.y;
+    const uint32_t* row = wm_row(wm, past + b * past_stride, t);
+    if (!row) return;
+    float* lg = logits + b * V;
+    const float d = wm.delta;
+    for (long long w = blockIdx.x * blockDim.x + threadIdx.x; w * 32 < V; w += (long long)gridDim.x * blockDim.x) {
+        uint32_t bits = row[w];
+        if (!bits) continue;
+        long long v0 = w * 32;
+        for (int j = 0; j < 32 && v0 + j < V; ++j)
+            if ((bits >> j) & 1u) lg[v0 + j] = lg[v0 + j] + d;
+    }
+}
+
+// ---------------------------------------------------------------------- fused sampler
+constexpr int SAMP_THREADS = 1024;
+constexpr int SAMP_WAVES = SAMP_THREADS / 64;
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Block-wide order-independent reductions through LDS.
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long* red) {
+    v = wave_sum_u64(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    unsigned long long s = 0;
+    for (int i = 0; i < SAMP_WAVES; ++i) s += red[i];
+    return s;
+}
+
+__device__ __forceinline__ uint32_t block_max_u32(uint32_t v, unsigned long long* red) {
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    uint32_t s = 0;
+    for (int i = 0; i < SAMP_WAVES; ++i) s = max(s, (uint32_t)red[i]);
+    return s;
+}
+
+// Wave 0 scans a 256-bucket u64 histogram.
+//  DESC_COUNT: from bucket 255 downwards, first bucket where the running count reaches `need`;
+//              returns bucket, and *above = count strictly above it.
+//  ASC_MASS:   from bucket 0 upwards, first bucket whose inclusive mass (base + ...) converts to
+//              an fp32 value > thr; returns bucket (or -1 if none), *above = mass strictly below it.
+template <bool ASC_MASS>
+__device__ __forceinline__ int scan_hist(const unsigned long long* hist, unsigned long long need_or_base, float thr,
+                                         unsigned long long* other) {
+    const int l = threadIdx.x & 63;
+    unsigned long long h0, h1, h2, h3;
+    if (ASC_MASS) {
+        h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+    } else {  // reversed order: lane l covers buckets 255-4l .. 252-4l
+        h0 = hist[255 - 4 * l], h1 = hist[254 - 4 * l], h2 = hist[253 - 4 * l], h3 = hist[252 - 4 * l];
+    }
+    unsigned long long tot = h0 + h1 + h2 + h3;
+    unsigned long long inc = tot;
+    for (int o = 1; o < 64; o <<= 1) {
+        unsigned long long n = __shfl_up(inc, o);
+        if (l >= o) inc += n;
+    }
+    unsigned long long exc = inc - tot;  // sum of all earlier lanes' buckets
+    unsigned long long c0 = exc + h0, c1 = c0 + h1, c2 = c1 + h2, c3 = c2 + h3;
+    int hit = -1;
+    unsigned long long before = 0;
+    if (ASC_MASS) {
+        const unsigned long long base = need_or_base;
+        if (!(wmar_fx_to_f32(base + c0) <= thr)) { hit = 0; before = exc; }
+        else if (!(wmar_fx_to_f32(base + c1) <= thr)) { hit = 1; before = c0; }
+        else if (!(wmar_fx_to_f32(base + c2) <= thr)) { hit = 2; before = c1; }
+        else if (!(wmar_fx_to_f32(base + c3) <= thr)) { hit = 3; before = c2; }
+    } else {
+        const unsigned long long need = need_or_base;
+        if (c0 >= need) { hit = 0; before = exc; }
+        else if (c1 >= need) { hit = 1; before = c0; }
+        else if (c2 >= need) { hit = 2; before = c1; }
+        else if (c3 >= need) { hit = 3; before = c2; }
+    }
+    unsigned long long m = __ballot(hit >= 0);
+    if (m == 0) { *other = inc; return -1; }  // (only lane 63's value is the total; unused by callers)
+    int first = __ffsll((long long)m) - 1;
+    int hit_f = __shfl(hit, first);
+    unsigned long long before_f = __shfl(before, first);
+    *other = before_f;
+    int bucket = 4 * first + hit_f;
+    return ASC_MASS ? bucket : 255 - bucket;
+}
+
+__global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
+    __shared__ unsigned long long hist[256];
+    __shared__ unsigned long long red[SAMP_WAVES];
+    __shared__ unsigned long long sh_u64[2];
+    __shared__ int sh_i[2];
+    __shared__ float red_f[SAMP_WAVES];
+    __shared__ int red_i[SAMP_WAVES];
+
+    const long long b = blockIdx.x;
+    const long long V = a.V;
+    const int tid = threadIdx.x;
+    const long long t = a.t_dev ? (long long)*a.t_dev : a.t_host;
+    const long long step = a.step_dev ? (long long)*a.step_dev : 0;
+    const long long* past = a.past ? a.past + b * a.past_stride : nullptr;
+    const uint32_t* grow = past ? wm_row(a.wm, past, t) : nullptr;
+    const float* lg = a.logits + b * V;
+    const float* q = a.q + step * a.q_step_stride + b * V;
+    float* x = a.scratch + b * V;
+    float* trace = a.trace ? a.trace + (step * a.B + b) * V : nullptr;
+    const float T = a.temperature;
+    const float delta = a.wm.delta;
+
+    // P0: bias, temperature, row max
+    uint32_t kmax = 0;
+    for (long long v = tid; v < V; v += SAMP_THREADS) {
+        float xv = lg[v];
+        if (trace) trace[v] = xv;
+        if (grow && ((grow[v >> 5] >> (v & 31)) & 1u)) xv = xv + delta;
+        xv = xv / T;
+        x[v] = xv;
+        kmax = max(kmax, wmar_f32_key(xv));
+    }
+    kmax = block_max_u32(kmax, red);
+    const float m = wmar_key_f32(kmax);
+    const uint32_t NEG_INF_KEY = 0x007fffffu;  // wmar_f32_key(-inf)
+
+    // top-k: exact k-th largest key by 4 radix passes (count histograms)
+    uint32_t thr_key = 0;
+    if (a.top_k > 0 && (long long)a.top_k < V) {
+        uint32_t prefix = 0, mask = 0;
+        unsigned long long need = (unsigned long long)a.top_k;
+        for (int pass = 3; pass >= 0; --pass) {
+            for (int i = tid; i < 256; i += SAMP_THREADS) hist[i] = 0;
+            __syncthreads();
+            for (long long v = tid; v < V; v += SAMP_THREADS) {
+                uint32_t k = wmar_f32_key(x[v]);
+                if ((k & mask) == prefix) atomicAdd(&hist[(k >> (8 * pass)) & 255u], 1ull);
+            }
+            __syncthreads();
+            if (tid < 64) {
+                unsigned long long above;
+                int bkt = scan_hist<false>(hist, need, 0.f, &above);
+                if (tid == 0) { sh_i[0] = bkt; sh_u64[0] = above; }
+            }
+            __syncthreads();
+            prefix |= (uint32_t)sh_i[0] << (8 * pass);
+            mask |= 0xffu << (8 * pass);
+            need -= sh_u64[0];
+            __syncthreads();
+        }
+        thr_key = prefix;
+    }
+    if (thr_key <= NEG_INF_KEY) thr_key = NEG_INF_KEY + 1;  // -inf entries are never alive
+
+    // top-p: boundary (K*, i*) of the ascending (value, index) order by mass-radix descent
+    uint32_t bkey = 0;       // kept  <=>  key >= thr_key && (key > bkey || (key == bkey && idx >= bidx))
+    long long bidx = 0;
+    if (a.use_top_p) {
+        unsigned long long S = 0;
+        for (long long v = tid; v < V; v += SAMP_THREADS) {
+            float xv = x[v];
+            if (wmar_f32_key(xv) >= thr_key) S += wmar_fx(wmar_expf(xv - m));
+        }
+        S = block_sum_u64(S, red);
+        const float Sf = wmar_fx_to_f32(S);
+        const float thr = a.top_p_thr;
+        uint32_t prefix = 0, mask = 0;
+        unsigned long long base = 0;
+        bool all_pass = false;
+        for (int pass = 3; pass >= 0 && !all_pass; --pass) {
+            for (int i = tid; i < 256; i += SAMP_THREADS) hist[i] = 0;
+            __syncthreads();
+            for (long long v = tid; v < V; v += SAMP_THREADS) {
+                float xv = x[v];
+                uint32_t k = wmar_f32_key(xv);
+                if (k >= thr_key && (k & mask) == prefix)
+                    atomicAdd(&hist[(k >> (8 * pass)) & 255u], wmar_fx(wmar_expf(xv - m) / Sf));
+            }
+            __syncthreads();
+            if (tid < 64) {
+                unsigned long long below;
+                int bkt = scan_hist<true>(hist, base, thr, &below);
+                if (tid == 0) { sh_i[0] = bkt; sh_u64[0] = below; }
+            }
+            __syncthreads();
+            int bkt = sh_i[0];
+            unsigned long long below = sh_u64[0];
+            __syncthreads();
+            if (bkt < 0) { all_pass = true; break; }
+            prefix |= (uint32_t)bkt << (8 * pass);
+            mask |= 0xffu << (8 * pass);
+            base += below;
+        }
+        if (!all_pass) {
+            // ties at the boundary value: refine on the index (ascending), 8 bits at a time
+            bkey = prefix;
+            unsigned long long cnt = 0;
+            for (long long v = tid; v < V; v += SAMP_THREADS) cnt += (wmar_f32_key(x[v]) == bkey);
+            cnt = block_sum_u64(cnt, red);
+            if (cnt > 1) {
+                uint32_t ipre = 0, imask = 0;
+                for (int pass = 3; pass >= 0; --pass) {
+                    for (int i = tid; i < 256; i += SAMP_THREADS) hist[i] = 0;
+                    __syncthreads();
+                    for (long long v = tid; v < V; v += SAMP_THREADS) {
+                        float xv = x[v];
+                        if (wmar_f32_key(xv) == bkey && (((uint32_t)v) & imask) == ipre)
+                            atomicAdd(&hist[(((uint32_t)v) >> (8 * pass)) & 255u], wmar_fx(wmar_expf(xv - m) / Sf));
+                    }
+                    __syncthreads();
+                    if (tid < 64) {
+                        unsigned long long below;
+                        int bkt = scan_hist<true>(hist, base, thr, &below);
+                        if (tid == 0) { sh_i[0] = bkt; sh_u64[0] = below; }
+                    }
+                    __syncthreads();
+                    int bkt = sh_i[0];
+                    unsigned long long below = sh_u64[0];
+                    __syncthreads();
+                    // the boundary value's bucket failed as a whole, so some index bucket fails too
+                    ipre |= (uint32_t)(bkt < 0 ? 255 : bkt) << (8 * pass);
+                    imask |= 0xffu << (8 * pass);
+                    base += below;
+                }
+                bidx = (long long)ipre;
+            }
+        } else {
+            // everything satisfies cum <= thr: only the last element of the order survives
+            bkey = kmax;
+            uint32_t imax = 0;
+            for (long long v = tid; v < V; v += SAMP_THREADS)
+                if (wmar_f32_key(x[v]) == kmax) imax = max(imax, (uint32_t)v);
+            bidx = (long long)block_max_u32(imax, red);
+        }
+    }
+
+    // final softmax over the kept set + exponential race argmax(p / q), first index on ties
+    unsigned long long S2 = 0;
+    for (long long v = tid; v < V; v += SAMP_THREADS) {
+        float xv = x[v];
+        uint32_t k = wmar_f32_key(xv);
+        bool kept = k >= thr_key && (k > bkey || (k == bkey && v >= bidx));
+        if (kept) S2 += wmar_fx(wmar_expf(xv - m));
+    }
+    S2 = block_sum_u64(S2, red);
+    const float Sf2 = wmar_fx_to_f32(S2);
+    float best = -INFINITY;
+    int besti = 0;
+    for (long long v = tid; v < V; v += SAMP_THREADS) {
+        float xv = x[v];
+        uint32_t k = wmar_f32_key(xv);
+        bool kept = k >= thr_key && (k > bkey || (k == bkey && v >= bidx));
+        float e = kept ? wmar_expf(xv - m) : 0.0f;
+        float r = (e / Sf2) / q[v];
+        if (r > best) { best = r; besti = (int)v; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        float ob = __shfl_xor(best, o);
+        int oi = __shfl_xor(besti, o);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    if ((tid & 63) == 0) { red_f[tid >> 6] = best; red_i[tid >> 6] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < SAMP_WAVES; ++i)
+            if (red_f[i] > best || (red_f[i] == best && red_i[i] < besti)) { best = red_f[i]; besti = red_i[i]; }
+        a.tok_out[b * a.tok_out_stride + step] = besti;
+        if (a.past_append) a.past_append[b * a.past_stride + t] = besti;
+    }
+}
+
+// ---------------------------------------------------------------------------- detector
+struct DetArgs {
+    WmDev wm;
+    double gamma;
+    const long long* codes;
+    long long L;
+    int* n_scored;
+    int* n_green;
+    double* pval;
+    signed char* mask;
+    long long mask_stride;
+};
+
+__device__ __forceinline__ long long det_num_ngrams(int seed_mode, int h, long long L, long long S) {
+    if (seed_mode != WMAR_SEED_SPATIAL) return L - h;
+    if (h == 1) return L - 1;            // every cell except (0,0)
+    return (S - 1) * (S - 1);            // 2x2 blocks
+}
+
+// i-th n-gram of the enumeration in gentime_watermark.py:33-88, as positions into codes
+__device__ __forceinline__ void det_ngram_pos(int seed_mode, int h, long long S, long long i, long long* pos) {
+    if (seed_mode != WMAR_SEED_SPATIAL) {
+        for (int j = 0; j <= h; ++j) pos[j] = i + j;
+    } else if (h == 1) {
+        long long cell = i + 1;          // row-major cell index, (0,0) skipped
+        long long r = cell / S, c = cell % S;
+        pos[0] = (c == 0) ? (r - 1) * S : cell - 1;
+        pos[1] = cell;
+    } else {
+        long long r = i / (S - 1), c = i % (S - 1);
+        pos[0] = r * S + c; pos[1] = r * S + c + 1; pos[2] = (r + 1) * S + c; pos[3] = (r + 1) * S + c + 1;
+    }
+}
+
+__device__ double betainc_int(long long a, long long bb, double x) {
+    if (a <= 0) return __longlong_as_double(0x7ff8000000000000ll);
+    long long n = a + bb - 1;
+    double lt = lgamma((double)n + 1.0) - lgamma((double)a + 1.0) - lgamma((double)(n - a) + 1.0) +
+                (double)a * log(x) + (double)(n - a) * log1p(-x);
+    double term = exp(lt), sum = term;
+    double odds = x / (1.0 - x);
+    for (long long k = a; k < n; ++k) {
+        term *= ((double)(n - k) / (double)(k + 1)) * odds;
+        sum += term;
+    }
+    return sum > 1.0 ? 1.0 : sum;
+}
+
+__global__ __launch_bounds__(256) void k_detect(DetArgs a) {
+    __shared__ int red_s[4], red_g[4];
+    const long long b = blockIdx.x;
+    const long long* codes = a.codes + b * a.L;
+    const int h = a.wm.h, n = h + 1;
+    long long S = 0;
+    if (a.wm.seed_mode == WMAR_SEED_SPATIAL) {
+        S = (long long)(sqrt((double)a.L) + 0.5);
+    }
+    const long long cnt = det_num_ngrams(a.wm.seed_mode, h, a.L, S);
+    signed char* mask = a.mask ? a.mask + b * a.mask_stride : nullptr;
+    if (mask)
+        for (int i = threadIdx.x; i < h; i += blockDim.x) mask[i] = -1;
+    int ns = 0, ng = 0;
+    for (long long i = threadIdx.x; i < cnt; i += blockDim.x) {
+        long long pi[4], pj[4], ti[4];
+        det_ngram_pos(a.wm.seed_mode, h, S, i, pi);
+        for (int k = 0; k < n; ++k) ti[k] = codes[pi[k]];
+        bool dup = false;
+        for (long long j = 0; j < i && !dup; ++j) {
+            det_ngram_pos(a.wm.seed_mode, h, S, j, pj);
+            bool same = true;
+            for (int k = 0; k < n; ++k) same = same && (codes[pj[k]] == ti[k]);
+            dup = same;
+        }
+        int g = 0;
+        if (!dup) {
+            long long sum = 0;
+            for (int k = 0; k < h; ++k) sum += ti[k];
+            long long row = a.wm.seed_mode == WMAR_SEED_FIXED ? 0 : sum;
+            long long tgt = ti[h];
+            if (row >= 0 && row < a.wm.n_rows && tgt >= 0 && tgt < a.wm.row_words * 32)
+                g = (a.wm.table[row * a.wm.row_words + (tgt >> 5)] >> (tgt & 31)) & 1u;
+            ns += 1;
+            ng += g;
+        }
+        if (mask) mask[h + i] = dup ? -1 : (signed char)g;
+    }
+    for (int o = 32; o > 0; o >>= 1) { ns += __shfl_xor(ns, o); ng += __shfl_xor(ng, o); }
+    if ((threadIdx.x & 63) == 0) { red_s[threadIdx.x >> 6] = ns; red_g[threadIdx.x >> 6] = ng; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ns = red_s[0] + red_s[1] + red_s[2] + red_s[3];
+        ng = red_g[0] + red_g[1] + red_g[2] + red_g[3];
+        a.n_scored[b] = ns;
+        a.n_green[b] = ng;
+        a.pval[b] = betainc_int(ng, 1 + (long long)ns - ng, a.gamma);
+    }
+}
+
+// Launch helper shared with the generation graph (gpt.hip).
+int launch_sample_fused(const SampArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_sample_fused, dim3((unsigned)a.B), dim3(SAMP_THREADS), 0, st, a);
+    return launch_status("k_sample_fused");
+}
+
+}  // namespace wmar
+
+using namespace wmar;
+
+static int check_wm(const wmar_wm_ctx* wm, int64_t V) {
+    WMAR_REQUIRE(wm->table_dev && wm->n_rows > 0, "watermark table missing");
+    WMAR_REQUIRE(wm->vocab_size == V, "watermark vocab %lld != logits vocab %lld", (long long)wm->vocab_size, (long long)V);
+    WMAR_REQUIRE(wm->seed_strategy >= 0 && wm->seed_strategy <= 2, "bad seed strategy");
+    if (wm->seed_strategy == WMAR_SEED_SPATIAL)
+        WMAR_REQUIRE(wm->context_size == 1 || wm->context_size == 3,
+                     "Spatial seeding only implemented for context size in [1,3]");
+    WMAR_REQUIRE(wm->context_size >= 0 && wm->context_size <= 3, "context size %d unsupported (0..3)", wm->context_size);
+    return WMAR_OK;
+}
+
+extern "C" {
+
+int wmar_wm_process_logits(const wmar_wm_ctx* wm, float* logits_dev, int64_t B, const int64_t* past_ids_dev,
+                           int64_t t, int64_t past_stride, void* stream) {
+    WMAR_REQUIRE(wm && logits_dev && (past_ids_dev || wm->seed_strategy == WMAR_SEED_FIXED), "process_logits: null argument");
+    if (int rc = check_wm(wm, wm->vocab_size)) return rc;
+    if (B == 0) return WMAR_OK;
+    WmDev d = make_wm(wm);
+    long long words = d.row_words;
+    dim3 grid((unsigned)((words + 255) / 256), (unsigned)B);
+    hipLaunchKernelGGL(k_wm_bias, grid, dim3(256), 0, (hipStream_t)stream, d, logits_dev, (long long)wm->vocab_size,
+                       (const long long*)past_ids_dev, (long long)t, (long long)past_stride);
+    return launch_status("k_wm_bias");
+}
+
+int wmar_sample_fused(const wmar_wm_ctx* wm, const float* logits_dev, int64_t B, int64_t V,
+                      const int64_t* past_ids_dev, int64_t t, int64_t past_stride, float temperature,
+                      int32_t top_k, double top_p, const float* q_dev, float* scratch_dev,
+                      int64_t* tok_out_dev, void* stream) {
+    WMAR_REQUIRE(logits_dev && q_dev && scratch_dev && tok_out_dev, "sample_fused: null argument");
+    WMAR_REQUIRE(V > 0 && V < (1ll << 31), "sample_fused: bad vocab");
+    WMAR_REQUIRE(!(top_p >= 0) || top_p <= 1.0, "`top_p` has to be a float > 0 and < 1, but is %f", top_p);
+    if (wm) {
+        if (int rc = check_wm(wm, V)) return rc;
+        WMAR_REQUIRE(past_ids_dev || wm->seed_strategy == WMAR_SEED_FIXED, "sample_fused: past_ids required");
+    }
+    if (B == 0) return WMAR_OK;
+    SampArgs a{};
+    a.wm = make_wm(wm);
+    a.logits = logits_dev;
+    a.V = V;
+    a.past = (const long long*)past_ids_dev;
+    a.past_stride = past_stride;
+    a.t_host = t;
+    a.temperature = temperature;
+    a.top_k = top_k;
+    a.use_top_p = top_p >= 0;
+    a.top_p_thr = (float)(1.0 - top_p);
+    a.q = q_dev;
+    a.scratch = scratch_dev;
+    a.tok_out = (long long*)tok_out_dev;
+    a.tok_out_stride = 1;
+    a.B = B;
+    return launch_sample_fused(a, (hipStream_t)stream);
+}
+
+int64_t wmar_detect_num_ngrams(int32_t seed_strategy, int32_t context_size, int64_t L) {
+    if (seed_strategy != WMAR_SEED_SPATIAL) return L - context_size;
+    long long S = (long long)(sqrt((double)L) + 0.5);
+    if (S * S != L) return WMAR_EINVAL;
+    return context_size == 1 ? L - 1 : (S - 1) * (S - 1);
+}
+
+int wmar_detect(const wmar_wm_ctx* wm, double gamma, const int64_t* codes_dev, int64_t B, int64_t L,
+                int32_t* n_scored_dev, int32_t* n_green_dev, double* pval_dev, int8_t* mask_dev,
+                int64_t mask_stride, void* stream) {
+    WMAR_REQUIRE(wm && codes_dev && n_scored_dev && n_green_dev && pval_dev, "detect: null argument");
+    if (int rc = check_wm(wm, wm->vocab_size)) return rc;
+    if (L - wm->context_size < 1) {
+        set_error("Must have at least 1 token to score after the first min_context_len=%d tokens required by the seeding scheme.",
+                  wm->context_size);
+        return WMAR_ESHORT;
+    }
+    if (wm->seed_strategy == WMAR_SEED_SPATIAL) {
+        long long S = (long long)(sqrt((double)L) + 0.5);
+        WMAR_REQUIRE(S * S == L, "Sequence must be a square");
+    }
+    if (mask_dev) WMAR_REQUIRE(mask_stride >= wm->context_size + wmar_detect_num_ngrams(wm->seed_strategy, wm->context_size, L),
+                               "detect: mask stride too small");
+    if (B == 0) return WMAR_OK;
+    DetArgs a{};
+    a.wm = make_wm(wm);
+    a.gamma = gamma;
+    a.codes = (const long long*)codes_dev;
+    a.L = L;
+    a.n_scored = n_scored_dev;
+    a.n_green = n_green_dev;
+    a.pval = pval_dev;
+    a.mask = (signed char*)mask_dev;
+    a.mask_stride = mask_stride;
+    hipLaunchKernelGGL(k_detect, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_status("k_detect");
+}
+
+}  // extern "C"

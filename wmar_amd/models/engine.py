@@ -1,0 +1,156 @@
+"""Python handles on the native engines of libwmar_hip.so (GPT decode loop, VQGAN)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from .. import _lib
+from ..utils.synth import GPTConfig, VQConfig
+
+
+def _require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"wmar_amd: {what} must live on the MI355X (no CPU implementation)")
+
+
+class GPTEngine:
+    """minGPT with a static KV cache; replaces GPT.forward_with_past + sample_with_past
+    (deps/taming/modules/transformer/mingpt.py:183-214, 326-368)."""
+
+    def __init__(self, cfg: GPTConfig, state: Dict[str, torch.Tensor], max_batch: int = 64, device="cuda"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.max_batch = int(max_batch)
+        L = _lib.load()
+        tensors = {}
+        for k, v in state.items():
+            if k.endswith("attn.mask"):
+                continue
+            t = v.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            tensors[k] = t
+        names, ptrs, n = _lib.tensor_table(tensors)
+        c = _lib.GptConfig(cfg.vocab_size, cfg.block_size, cfg.n_layer, cfg.n_head, cfg.n_embd, self.max_batch)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(L.wmar_gpt_create(C.byref(c), names, ptrs, n, _lib.stream_ptr(self.device), C.byref(h)))
+        self._h = h
+        self._L = L
+        del tensors  # weights were repacked into the engine's own HBM buffers
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.wmar_gpt_destroy(h)
+            self._h = None
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self._L.wmar_gpt_device_bytes(self._h))
+
+    def decode_step(self, tok: torch.Tensor, pos: int) -> torch.Tensor:
+        """One token per sequence at position `pos` -> logits [B, V]."""
+        _require_cuda(tok, "tokens")
+        tok = tok.to(torch.int64).contiguous().view(-1)
+        B = tok.shape[0]
+        logits = torch.empty(B, self.cfg.vocab_size, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.wmar_gpt_decode_step(self._h, tok.data_ptr(), B, int(pos), logits.data_ptr(),
+                                                    _lib.stream_ptr(self.device)))
+        return logits
+
+    def generate(self, cond: torch.Tensor, steps: int, q: torch.Tensor, temperature=1.0, top_k=None, top_p=None,
+                 wm_ctx: Optional[_lib.WmCtx] = None, use_graph: bool = True, trace_logits: bool = False):
+        """sample_with_past: cond int64 [B], q float32 [steps, B, V] -> tokens int64 [B, steps]."""
+        _require_cuda(cond, "conditioning")
+        _require_cuda(q, "q")
+        cond = cond.to(torch.int64).contiguous().view(-1)
+        B = cond.shape[0]
+        V = self.cfg.vocab_size
+        assert q.shape == (steps, B, V) and q.dtype == torch.float32 and q.is_contiguous()
+        out = torch.empty(B, steps, dtype=torch.int64, device=self.device)
+        trace = torch.empty(steps, B, V, dtype=torch.float32, device=self.device) if trace_logits else None
+        sp = _lib.SampleParams(float(temperature), int(top_k) if top_k else 0,
+                               float(top_p) if top_p is not None else -1.0, 1 if use_graph else 0)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.wmar_gpt_generate(
+                self._h, C.byref(wm_ctx) if wm_ctx is not None else None, C.byref(sp), cond.data_ptr(), B, int(steps),
+                q.data_ptr(), out.data_ptr(), trace.data_ptr() if trace is not None else None,
+                _lib.stream_ptr(self.device)))
+        return (out, trace) if trace_logits else out
+
+    def set_timing(self, on: bool):
+        self._L.wmar_gpt_set_timing(self._h, 1 if on else 0)
+
+    def get_timing(self):
+        arr = (C.c_double * 5)()
+        self._L.wmar_gpt_get_timing(self._h, arr)
+        return list(arr)
+
+
+class VQGANEngine:
+    """Taming VQGAN encode / decode; replaces VQModel.encode/decode + VectorQuantizer2
+    (deps/taming/models/vqgan.py:64-73, modules/vqvae/quantize.py:272-331)."""
+
+    def __init__(self, cfg: VQConfig, state: Dict[str, torch.Tensor], max_batch: int = 64, device="cuda"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.max_batch = int(max_batch)
+        L = _lib.load()
+        tensors = {k: v.detach().to(device=self.device, dtype=torch.float32).contiguous() for k, v in state.items()
+                   if not k.startswith("loss.")}
+        names, ptrs, n = _lib.tensor_table(tensors)
+        c = _lib.VqConfig()
+        c.ch, c.num_res_blocks, c.resolution = cfg.ch, cfg.num_res_blocks, cfg.resolution
+        c.in_channels, c.out_ch, c.z_channels = cfg.in_channels, cfg.out_ch, cfg.z_channels
+        c.embed_dim, c.n_embed, c.n_levels = cfg.embed_dim, cfg.n_embed, len(cfg.ch_mult)
+        for i, m in enumerate(cfg.ch_mult):
+            c.ch_mult[i] = m
+        c.n_attn_res = len(cfg.attn_resolutions)
+        for i, r in enumerate(cfg.attn_resolutions):
+            c.attn_resolutions[i] = r
+        c.max_batch = self.max_batch
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(L.wmar_vq_create(C.byref(c), names, ptrs, n, _lib.stream_ptr(self.device), C.byref(h)))
+        self._h = h
+        self._L = L
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.wmar_vq_destroy(h)
+            self._h = None
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self._L.wmar_vq_device_bytes(self._h))
+
+    def decode(self, codes: torch.Tensor) -> torch.Tensor:
+        _require_cuda(codes, "codes")
+        codes = codes.to(torch.int64).contiguous()
+        B = codes.shape[0]
+        R = self.cfg.resolution
+        out = torch.empty(B, self.cfg.out_ch, R, R, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            for b0 in range(0, B, self.max_batch):
+                b1 = min(B, b0 + self.max_batch)
+                _lib.check(self._L.wmar_vq_decode(self._h, codes[b0:b1].data_ptr(), b1 - b0, out[b0:b1].data_ptr(),
+                                                  _lib.stream_ptr(self.device)))
+        return out
+
+    def encode(self, images: torch.Tensor, return_prequant: bool = False):
+        _require_cuda(images, "images")
+        images = images.to(torch.float32).contiguous()
+        B = images.shape[0]
+        S = self.cfg.codes_size
+        codes = torch.empty(B, S * S, dtype=torch.int64, device=self.device)
+        pre = torch.empty(B * S * S, self.cfg.embed_dim, dtype=torch.float32, device=self.device) if return_prequant else None
+        with torch.cuda.device(self.device):
+            for b0 in range(0, B, self.max_batch):
+                b1 = min(B, b0 + self.max_batch)
+                _lib.check(self._L.wmar_vq_encode(
+                    self._h, images[b0:b1].data_ptr(), b1 - b0, codes[b0:b1].data_ptr(),
+                    pre[b0 * S * S:b1 * S * S].data_ptr() if pre is not None else None, _lib.stream_ptr(self.device)))
+        return (codes, pre) if return_prequant else codes
