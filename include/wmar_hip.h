@@ -147,10 +147,23 @@ int wmar_gpt_generate(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_para
                       int64_t B, int32_t steps, const float* q_dev, int64_t* tokens_out_dev,
                       float* logits_trace_dev, void* stream);
 
-/* per-kernel-class device time of the last wmar_gpt_generate with timing enabled (ms):
- * [0]=gemm [1]=attention [2]=residual/LN [3]=sampler [4]=total step avg.  Debug aid for bench.py. */
+/* Per-kernel-class device times of the last wmar_gpt_generate call, measured with HIP events
+ * recorded on the caller's stream around every launch.  Only available for eager runs
+ * (use_graph = 0) after wmar_gpt_set_timing(g, 1); used by bench.py for the roofline line.
+ * Classes: */
+#define WMAR_T_EMBED 0   /* token+position embedding, LN statistics            */
+#define WMAR_T_QKV 1     /* LN1 -> QKV GEMM -> KV cache                         */
+#define WMAR_T_ATTN 2    /* decode attention                                   */
+#define WMAR_T_PROJ 3    /* attention output projection (split-K slabs)        */
+#define WMAR_T_RESID 4   /* residual fold + LN statistics                      */
+#define WMAR_T_FC1 5     /* LN2 -> FC1 GEMM -> GELU                             */
+#define WMAR_T_FC2 6     /* FC2 GEMM (split-K slabs)                           */
+#define WMAR_T_HEAD 7    /* ln_f -> vocabulary head GEMM                       */
+#define WMAR_T_SAMPLE 8  /* fused watermark + sampling                         */
+#define WMAR_T_NCLASS 9
 int wmar_gpt_set_timing(wmar_gpt* g, int32_t enabled);
-int wmar_gpt_get_timing(wmar_gpt* g, double* out5);
+/* total_us[c], calls[c] for each class; *step_ms = average wall time of one decode step (any mode). */
+int wmar_gpt_get_timing(wmar_gpt* g, double* total_us, int64_t* calls, double* step_ms);
 
 /* ---------------------------------------------------------------------- VQGAN
  * Taming VQGAN (deps/taming/models/vqgan.py:30-73, modules/diffusionmodules/model.py:343-538,

@@ -1,0 +1,78 @@
+"""HIP VQGAN engine against the torch-fp32 oracle and the reference's golden images/codes."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import model_oracle as M  # noqa: E402
+from wmar_amd.utils import synth  # noqa: E402
+
+SMALL_VQ = synth.VQConfig(ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(8,), resolution=32,
+                          z_channels=16, embed_dim=8, n_embed=512)
+# a second shape family: 2 res blocks, 4 levels, attention at two resolutions, wider channels
+MID_VQ = synth.VQConfig(ch=32, ch_mult=(1, 1, 2, 4), num_res_blocks=2, attn_resolutions=(8, 16), resolution=64,
+                        z_channels=32, embed_dim=16, n_embed=1024)
+
+
+@pytest.fixture(scope="module")
+def small():
+    from wmar_amd.models.engine import VQGANEngine
+    sd = synth.synth_vq_state(SMALL_VQ, seed=5)
+    return VQGANEngine(SMALL_VQ, sd, max_batch=8), sd
+
+
+def test_decode_golden(golden, small):
+    eng, _ = small
+    img = eng.decode(torch.from_numpy(golden["vq_codes"]).cuda()).cpu().numpy()
+    np.testing.assert_allclose(img, golden["vq_images"], rtol=0, atol=2e-4)
+
+
+def test_encode_golden(golden, small):
+    eng, _ = small
+    codes, pre = eng.encode(torch.from_numpy(golden["vq_images"]).cuda(), return_prequant=True)
+    np.testing.assert_allclose(pre.cpu().numpy(), golden["vq_prequant"], rtol=0, atol=2e-4)
+    assert np.array_equal(codes.cpu().numpy(), golden["vq_codes_roundtrip"])
+
+
+@pytest.mark.parametrize("B", [1, 3, 8])
+def test_roundtrip_vs_oracle(small, B):
+    eng, sd = small
+    rs = np.random.RandomState(B)
+    codes = torch.from_numpy(rs.randint(0, SMALL_VQ.n_embed, size=(B, SMALL_VQ.codes_size ** 2)).astype(np.int64))
+    ref_img = M.codes_to_images(sd, SMALL_VQ, codes)
+    img = eng.decode(codes.cuda())
+    np.testing.assert_allclose(img.cpu().numpy(), ref_img.numpy(), rtol=0, atol=2e-4)
+    # encode the ORACLE's image so both sides quantize the same input
+    ref_z = M.encode_prequant(sd, SMALL_VQ, ref_img)
+    got_codes, pre = eng.encode(ref_img.cuda(), return_prequant=True)
+    np.testing.assert_allclose(pre.cpu().numpy(), ref_z.numpy(), rtol=0, atol=2e-4)
+    ref_codes = M.quantize_argmin(sd["quantize.embedding.weight"], ref_z).view(B, -1)
+    agree = (got_codes.cpu() == ref_codes).float().mean().item()
+    assert agree == 1.0, agree
+
+
+def test_argmin_on_identical_vectors(small):
+    """Quantizer alone: feed the oracle's pre-quant vectors -> identical indices."""
+    eng, sd = small
+    rs = np.random.RandomState(9)
+    img = torch.from_numpy(rs.uniform(-1, 1, size=(4, 3, 32, 32)).astype(np.float32))
+    codes, pre = eng.encode(img.cuda(), return_prequant=True)
+    ref = M.quantize_argmin(sd["quantize.embedding.weight"], pre.cpu()).view(4, -1)
+    assert torch.equal(codes.cpu(), ref)
+
+
+def test_mid_config_vs_oracle():
+    from wmar_amd.models.engine import VQGANEngine
+    sd = synth.synth_vq_state(MID_VQ, seed=11)
+    eng = VQGANEngine(MID_VQ, sd, max_batch=4)
+    rs = np.random.RandomState(2)
+    codes = torch.from_numpy(rs.randint(0, MID_VQ.n_embed, size=(3, MID_VQ.codes_size ** 2)).astype(np.int64))
+    ref_img = M.codes_to_images(sd, MID_VQ, codes)
+    img = eng.decode(codes.cuda())
+    np.testing.assert_allclose(img.cpu().numpy(), ref_img.numpy(), rtol=0, atol=5e-4)
+    ref_z = M.encode_prequant(sd, MID_VQ, ref_img)
+    got_codes, pre = eng.encode(ref_img.cuda(), return_prequant=True)
+    np.testing.assert_allclose(pre.cpu().numpy(), ref_z.numpy(), rtol=0, atol=5e-4)
+    ref_codes = M.quantize_argmin(sd["quantize.embedding.weight"], ref_z).view(3, -1)
+    assert (got_codes.cpu() == ref_codes).float().mean().item() >= 0.99

@@ -97,7 +97,7 @@ def load():
     L.wmar_gpt_decode_step.argtypes = [vp, vp, i64, i32, vp, vp]
     L.wmar_gpt_generate.argtypes = [vp, C.POINTER(WmCtx), C.POINTER(SampleParams), vp, i64, i32, vp, vp, vp, vp]
     L.wmar_gpt_set_timing.argtypes = [vp, i32]
-    L.wmar_gpt_get_timing.argtypes = [vp, C.POINTER(f64)]
+    L.wmar_gpt_get_timing.argtypes = [vp, C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]
     if hasattr(L, "wmar_vq_create"):
         L.wmar_vq_create.argtypes = [C.POINTER(VqConfig), C.POINTER(C.c_char_p), C.POINTER(vp), i32, vp, C.POINTER(vp)]
         L.wmar_vq_destroy.argtypes = [vp]

@@ -25,13 +25,24 @@
 namespace wmar {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// streamed-once data (weights): non-temporal 16-byte load
+__device__ __forceinline__ float4 ld_nt(const float4* p) {
+    f32x4 v = __builtin_nontemporal_load((const f32x4*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 
 constexpr int MAX_SLABS = 8;
 constexpr int STAT_CHUNKS_MAX = 16;
+constexpr int GEMM_STAGE = 4;   // k-blocks (of 8) per register stage of the skinny GEMM
 
 // ------------------------------------------------------------------------ weight packing
+// gamma (nullable): the LayerNorm scale of the layer that feeds this Linear, folded into
+// the weights ( LN(x) W^T = xhat (W*gamma)^T + W beta ), so the GEMM's inner loop only
+// has to form xhat = (x - mean) * rstd.
 __global__ void k_pack_linear(const float* __restrict__ W, float4* __restrict__ Wp, int N, int K, int nt_off,
-                              int KB) {
+                              int KB, const float* __restrict__ gamma) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over (N/32)*KB*64
     long long total = (long long)(N / 32) * KB * 64;
     if (idx >= total) return;
@@ -42,7 +53,19 @@ __global__ void k_pack_linear(const float* __restrict__ W, float4* __restrict__ 
     int n = nt * 32 + (lane & 31);
     int k = kb * 8 + 4 * (lane >> 5);
     const float* src = W + (long long)n * K + k;
-    Wp[((long long)(nt + nt_off) * KB + kb) * 64 + lane] = make_float4(src[0], src[1], src[2], src[3]);
+    float4 v = make_float4(src[0], src[1], src[2], src[3]);
+    if (gamma) { v.x *= gamma[k]; v.y *= gamma[k + 1]; v.z *= gamma[k + 2]; v.w *= gamma[k + 3]; }
+    Wp[((long long)(nt + nt_off) * KB + kb) * 64 + lane] = v;
+}
+
+// out[n] = (bias ? bias[n] : 0) + sum_k W[n][k] * beta[k]   (one wave per output row)
+__global__ __launch_bounds__(64) void k_fold_bias(const float* __restrict__ W, const float* __restrict__ bias,
+                                                  const float* __restrict__ beta, float* __restrict__ out, int K) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    double acc = 0.0;
+    for (int k = lane; k < K; k += 64) acc += (double)W[(long long)n * K + k] * (double)beta[k];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) out[n] = (float)((bias ? (double)bias[n] : 0.0) + acc);
 }
 
 __global__ void k_set_int(int* p, int v) { *p = v; }
@@ -130,7 +153,7 @@ struct GemmArgs {
     const float* bias;         // [N] or null
     int KB, NT, MT, S;
     // fused LayerNorm on the B operand
-    const double* stats; int n_chunks; const float* gamma; const float* beta; int K;
+    const double* stats; int n_chunks; int K;
     // epilogues
     float4* out_packed; long long slab_stride;          // EPI_PACKED (slab s) / EPI_GELU
     float* qbuf; float* kcache; float* vcache;          // EPI_QKV
@@ -144,7 +167,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // grid = NT * (MT/MTW) * S workgroups of NW waves.  Each workgroup owns one 32-column
 // tile of the output for MTW row tiles and one K slice; its NW waves split that K slice
 // and reduce through LDS in a fixed order.
-template <int MTW, int NW, int EPI, bool LN>
+template <int MTW, int NW, int EPI, bool LN, int ABL = 0, int U = GEMM_STAGE, bool ROT = true>
 __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [NW][MTW*16][64]
     const int lane = threadIdx.x & 63;
@@ -186,34 +209,81 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
 
     const float4* Wp = a.Wp + (long long)nt * a.KB * 64 + lane;
     const float4* Xp = a.Xp + (long long)mt0 * 64 + lane;
-    const float4* g4 = (const float4*)a.gamma;
-    const float4* b4 = (const float4*)a.beta;
+    const long long xstep = (long long)a.MT * 64;
 
-#pragma unroll 4
-    for (int kb = kb0; kb < kb1; ++kb) {
-        float4 wv = Wp[(long long)kb * 64];
-        float4 xv[MTW];
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) xv[i] = Xp[((long long)kb * a.MT + i) * 64];
-        if (LN) {
-            float4 g = g4[kb * 2 + half], bt = b4[kb * 2 + half];
-#pragma unroll
-            for (int i = 0; i < MTW; ++i) {
-                xv[i].x = (xv[i].x - mu[i]) * rstd[i] * g.x + bt.x;
-                xv[i].y = (xv[i].y - mu[i]) * rstd[i] * g.y + bt.y;
-                xv[i].z = (xv[i].z - mu[i]) * rstd[i] * g.z + bt.z;
-                xv[i].w = (xv[i].w - mu[i]) * rstd[i] * g.w + bt.w;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, xv[i].x, acc[i], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, xv[i].y, acc[i], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, xv[i].z, acc[i], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, xv[i].w, acc[i], 0, 0, 0);
+    // Register double buffer: while the MFMAs of one stage (U k-blocks = 4U instructions per
+    // row tile) run, the loads of the next stage are in flight.
+    float4 wA[U], wB[U], xA[U][MTW], xB[U][MTW];
+#define WMAR_LOAD(WBUF, XBUF, KB0)                                                              \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                            \
+        const int kk = (KB0) + u;                                                               \
+        WBUF[u] = (ABL == 2) ? make_float4(1.f, 2.f, 3.f, (float)kk) : ld_nt(Wp + (long long)kk * 64); \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
+            XBUF[u][i] = (ABL == 1) ? make_float4(1.f, 2.f, 3.f, (float)kk) : Xp[(long long)kk * xstep + i * 64]; \
     }
+#define WMAR_MMA1(WV, XV)                                                                       \
+    {                                                                                           \
+        float4 xv[MTW];                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i) {                                      \
+            xv[i] = XV[i];                                                                      \
+            if (LN) {                                                                           \
+                xv[i].x = (xv[i].x - mu[i]) * rstd[i]; xv[i].y = (xv[i].y - mu[i]) * rstd[i];   \
+                xv[i].z = (xv[i].z - mu[i]) * rstd[i]; xv[i].w = (xv[i].w - mu[i]) * rstd[i];   \
+            }                                                                                   \
+        }                                                                                       \
+        if (ABL == 3) {                                                                         \
+            _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                    \
+                acc[i][0] += WV.x * xv[i].x + WV.y * xv[i].y + WV.z * xv[i].z + WV.w * xv[i].w; \
+        } else {                                                                                \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV.x, xv[i].x, acc[i], 0, 0, 0);      \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV.y, xv[i].y, acc[i], 0, 0, 0);      \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV.z, xv[i].z, acc[i], 0, 0, 0);      \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV.w, xv[i].w, acc[i], 0, 0, 0);      \
+        }                                                                                       \
+    }
+#define WMAR_MMA(WBUF, XBUF) _Pragma("unroll") for (int u = 0; u < U; ++u) WMAR_MMA1(WBUF[u], XBUF[u])
+    int kb = kb0;
+    const int nfull = (kb1 - kb0) / (2 * U);
+    if (nfull > 0) {
+        // Every workgroup of a launch walks the SAME activation rows.  Started in lockstep they
+        // would all hit the same few L2 channels at once (measured: 4.7 TB/s aggregate instead of
+        // >30), so each output tile starts its K walk at a different stage and wraps around.
+        // The summation order per tile stays fixed (it depends on the tile index only).
+        const int nst = 2 * nfull;
+        const int rot = (ROT ? (nt * 5 + mg * 3) : 0) % nst;
+#define WMAR_STAGE_KB(SI) (kb0 + (((SI) + rot) % nst) * U)
+        // sched_barrier(0): hipcc otherwise sinks every load down to its first use (it minimises
+        // registers), which serialises load -> wait -> 4 MFMAs.
+        WMAR_LOAD(wA, xA, WMAR_STAGE_KB(0))
+        __builtin_amdgcn_sched_barrier(0);
+        for (int it = 0; it < nfull; ++it) {
+            WMAR_LOAD(wB, xB, WMAR_STAGE_KB(2 * it + 1))
+            __builtin_amdgcn_sched_barrier(0);
+            WMAR_MMA(wA, xA)
+            __builtin_amdgcn_sched_barrier(0);
+            // last round: re-read an in-bounds stage instead of branching around the loads
+            WMAR_LOAD(wA, xA, WMAR_STAGE_KB((2 * it + 2) % nst))
+            __builtin_amdgcn_sched_barrier(0);
+            WMAR_MMA(wB, xB)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef WMAR_STAGE_KB
+        kb = kb0 + nst * U;
+    }
+    for (; kb < kb1; ++kb) {  // tail (slices that are not a multiple of 2U blocks)
+        float4 wv = ld_nt(Wp + (long long)kb * 64);
+        float4 xt[MTW];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) xt[i] = Xp[(long long)kb * xstep + i * 64];
+        WMAR_MMA1(wv, xt)
+    }
+#undef WMAR_MMA1
+#undef WMAR_LOAD
+#undef WMAR_MMA
 
     // in-workgroup K reduction (fixed order) + epilogue
     float* my = smem + (long long)w * (MTW * 16) * 64;
@@ -363,7 +433,7 @@ using namespace wmar;
 // ------------------------------------------------------------------------------ engine
 struct LayerW {
     float4 *wqkv, *wproj, *wfc1, *wfc2;
-    float *bqkv, *bproj, *bfc1, *bfc2, *ln1w, *ln1b, *ln2w, *ln2b;
+    float *bqkv, *bproj, *bfc1, *bfc2;
 };
 
 struct wmar_gpt {
@@ -372,7 +442,7 @@ struct wmar_gpt {
     std::vector<void*> allocs;
     int64_t bytes = 0;
     std::vector<LayerW> layers;
-    float *tok_emb = nullptr, *pos_emb = nullptr, *lnfw = nullptr, *lnfb = nullptr;
+    float *tok_emb = nullptr, *pos_emb = nullptr, *bhead = nullptr;
     float4* whead = nullptr;
     // workspaces
     float4 *x = nullptr, *y = nullptr, *hbuf = nullptr, *slabs = nullptr;
@@ -385,7 +455,42 @@ struct wmar_gpt {
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int timing = 0;
-    double times[5] = {0, 0, 0, 0, 0};
+    double step_ms = 0.0;
+    // per-launch event timing (eager mode only)
+    struct Span { int cls; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    bool span_on = false;
+    double cls_us[WMAR_T_NCLASS] = {0};
+    int64_t cls_calls[WMAR_T_NCLASS] = {0};
+    hipEvent_t next_event() {
+        if (ev_used == ev_pool.size()) {
+            hipEvent_t e = nullptr;
+            (void)hipEventCreate(&e);
+            ev_pool.push_back(e);
+        }
+        return ev_pool[ev_used++];
+    }
+    void span_begin(int cls, hipStream_t st) {
+        if (!span_on) return;
+        Span s{cls, next_event(), next_event()};
+        (void)hipEventRecord(s.a, st);
+        spans.push_back(s);
+    }
+    void span_end(hipStream_t st) {
+        if (!span_on) return;
+        (void)hipEventRecord(spans.back().b, st);
+    }
+    void span_collect() {
+        for (int i = 0; i < WMAR_T_NCLASS; ++i) { cls_us[i] = 0; cls_calls[i] = 0; }
+        for (auto& s : spans) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { cls_us[s.cls] += ms * 1000.0; cls_calls[s.cls] += 1; }
+        }
+        spans.clear();
+        ev_used = 0;
+    }
 
     template <typename T>
     int alloc(T** p, size_t n) {
@@ -405,6 +510,7 @@ struct wmar_gpt {
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
+        for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
     }
 };
 
@@ -420,10 +526,18 @@ struct TensorMap {
     }
 };
 
-int pack(wmar_gpt* g, const float* W, float4* Wp, int N, int K, int nt_off, hipStream_t st) {
+int pack(wmar_gpt* g, const float* W, float4* Wp, int N, int K, int nt_off, hipStream_t st,
+         const float* gamma = nullptr) {
     long long total = (long long)(N / 32) * (K / 8) * 64;
-    hipLaunchKernelGGL(k_pack_linear, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, Wp, N, K, nt_off, K / 8);
+    hipLaunchKernelGGL(k_pack_linear, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, Wp, N, K, nt_off, K / 8,
+                       gamma);
     return launch_status("k_pack_linear");
+}
+
+// dst[0..N) = bias + W beta
+int fold_bias(const float* W, const float* bias, const float* beta, float* dst, int N, int K, hipStream_t st) {
+    hipLaunchKernelGGL(k_fold_bias, dim3((unsigned)N), dim3(64), 0, st, W, bias, beta, dst, K);
+    return launch_status("k_fold_bias");
 }
 
 int copy_vec(wmar_gpt* g, float** dst, const float* src, size_t n, hipStream_t st) {
@@ -432,32 +546,53 @@ int copy_vec(wmar_gpt* g, float** dst, const float* src, size_t n, hipStream_t s
     return WMAR_OK;
 }
 
-template <int MTW, int NW, int EPI, bool LN>
+template <int MTW, int NW, int EPI, bool LN, int ABL = 0, int U = GEMM_STAGE, bool ROT = true>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
     const int grid = a.NT * (a.MT / MTW) * a.S;
     const size_t lds = (size_t)NW * MTW * 16 * 64 * sizeof(float);
-    hipLaunchKernelGGL((k_gemm<MTW, NW, EPI, LN>), dim3((unsigned)grid), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((k_gemm<MTW, NW, EPI, LN, ABL, U, ROT>), dim3((unsigned)grid), dim3(NW * 64), lds, st, a);
     return launch_status("k_gemm");
 }
 
-// Work split: enough workgroups to cover the 256 CUs; K slices never thinner than one 8-wide block.
-int pick_split(int NT, int groups, int KB, int NW) {
-    int want = (256 + NT * groups - 1) / (NT * groups);
-    int maxs = KB / NW;
-    if (maxs < 1) maxs = 1;
-    int S = want < 1 ? 1 : want;
-    if (S > maxs) S = maxs;
-    if (S > MAX_SLABS) S = MAX_SLABS;
-    return S;
+// Split-K factor for a GEMM whose partial slabs are folded by a later kernel: pick the S that
+// fills the 256 CUs most evenly (whole "rounds" of workgroups), keeping >= 8 k-blocks per wave.
+int pick_split(int tiles, int KB, int NW) {
+    int best = 1;
+    double best_eff = 0.0;
+    for (int S = 1; S <= MAX_SLABS; ++S) {
+        if (KB / (S * NW) < 8 && S > 1) break;
+        const int wgs = tiles * S;
+        const int rounds = (wgs + 255) / 256;
+        const double eff = (double)wgs / (rounds * 256.0);
+        if (eff > best_eff + 0.02) { best_eff = eff; best = S; }
+    }
+    return best;
 }
 
+// Row tiles per workgroup: two 32-row tiles share every weight fragment (half the operand
+// traffic per MFMA); a single tile when the batch has only one.
 template <int EPI, bool LN>
 int gemm_dispatch(GemmArgs a, bool allow_split, hipStream_t st) {
-    // one row tile per workgroup keeps >= 256 workgroups in flight for every shape of this model
     constexpr int NW = 4;
-    a.S = allow_split ? pick_split(a.NT, a.MT, a.KB, NW) : 1;
-    if (a.KB < NW * a.S) a.S = 1;
+    if (a.MT % 2 == 0) {
+        a.S = allow_split ? pick_split(a.NT * (a.MT / 2), a.KB, NW) : 1;
+        return launch_gemm<2, NW, EPI, LN>(a, st);
+    }
+    a.S = allow_split ? pick_split(a.NT * a.MT, a.KB, NW) : 1;
     return launch_gemm<1, NW, EPI, LN>(a, st);
+}
+
+// split-K GEMM writing partial slabs; reports the S it used
+int gemm_split(GemmArgs a, int* S_out, hipStream_t st) {
+    constexpr int NW = 4;
+    if (a.MT % 2 == 0) {
+        a.S = pick_split(a.NT * (a.MT / 2), a.KB, NW);
+        *S_out = a.S;
+        return launch_gemm<2, NW, EPI_PACKED, false>(a, st);
+    }
+    a.S = pick_split(a.NT * a.MT, a.KB, NW);
+    *S_out = a.S;
+    return launch_gemm<1, NW, EPI_PACKED, false>(a, st);
 }
 
 int stat_chunks(int KB) {
@@ -485,7 +620,9 @@ int enqueue_step(wmar_gpt* g, int64_t B, const StepIO& io, hipStream_t st) {
     r.x = g->x; r.stats = g->stats; r.KB = KBD; r.MT = MT; r.n_chunks = nch;
     r.tok_emb = g->tok_emb; r.pos_emb = g->pos_emb; r.tok = io.tok; r.tok_stride = io.tok_stride;
     r.tok_use_pos = io.tok_use_pos; r.pos_dev = g->pos_dev; r.B = (int)B; r.K = D;
+    g->span_begin(WMAR_T_EMBED, st);
     hipLaunchKernelGGL(k_resid_stats<true>, dim3(nch * MT), dim3(256), 0, st, r);
+    g->span_end(st);
     if ((rc = launch_status("k_resid_stats<embed>"))) return rc;
 
     int S_prev = 0;
@@ -493,7 +630,9 @@ int enqueue_step(wmar_gpt* g, int64_t B, const StepIO& io, hipStream_t st) {
     for (int l = 0; l <= g->L; ++l) {
         if (l > 0) {  // fold the previous layer's FC2 partial sums into the residual stream
             r.slabs = g->slabs; r.slab_stride = act; r.S = S_prev; r.bias = bias_prev;
+            g->span_begin(WMAR_T_RESID, st);
             hipLaunchKernelGGL(k_resid_stats<false>, dim3(nch * MT), dim3(256), 0, st, r);
+            g->span_end(st);
             if ((rc = launch_status("k_resid_stats"))) return rc;
         }
         if (l == g->L) break;
@@ -503,50 +642,66 @@ int enqueue_step(wmar_gpt* g, int64_t B, const StepIO& io, hipStream_t st) {
         a.pos_dev = g->pos_dev; a.D = D; a.H = g->H; a.hd = g->hd; a.Tmax = g->Tmax;
         // LN1 -> QKV (+bias) -> q buffer and KV cache
         a.Wp = w.wqkv; a.Xp = g->x; a.bias = w.bqkv; a.KB = KBD; a.NT = 3 * D / 32;
-        a.gamma = w.ln1w; a.beta = w.ln1b;
         a.qbuf = g->qbuf;
         const long long lstride = (long long)g->Bmax * g->H * g->Tmax * g->hd;
         a.kcache = g->kcache + l * lstride; a.vcache = g->vcache + l * lstride;
-        if ((rc = gemm_dispatch<EPI_QKV, true>(a, false, st))) return rc;
+        g->span_begin(WMAR_T_QKV, st);
+        rc = gemm_dispatch<EPI_QKV, true>(a, false, st);
+        g->span_end(st);
+        if (rc) return rc;
         // attention
         AttnArgs t{};
         t.qbuf = g->qbuf; t.kcache = a.kcache; t.vcache = a.vcache; t.y = g->y; t.pos_dev = g->pos_dev;
         t.D = D; t.H = g->H; t.Tmax = g->Tmax; t.MT = MT; t.scale = 1.0f / sqrtf((float)g->hd);
         const size_t lds = (size_t)g->Tmax * sizeof(float);
         const dim3 grid((unsigned)(B * g->H));
+        g->span_begin(WMAR_T_ATTN, st);
         if (g->hd == 64) hipLaunchKernelGGL(k_attn_decode<64>, grid, dim3(64), lds, st, t);
         else if (g->hd == 32) hipLaunchKernelGGL(k_attn_decode<32>, grid, dim3(64), lds, st, t);
         else hipLaunchKernelGGL(k_attn_decode<128>, grid, dim3(64), lds, st, t);
+        g->span_end(st);
         if ((rc = launch_status("k_attn_decode"))) return rc;
         // proj (split-K partial slabs; bias + residual folded by the next k_resid_stats)
         GemmArgs p = a;
         p.Wp = w.wproj; p.Xp = g->y; p.bias = nullptr; p.KB = KBD; p.NT = D / 32;
         p.out_packed = g->slabs; p.slab_stride = act;
-        p.S = pick_split(p.NT, MT, p.KB, 4);
-        if ((rc = launch_gemm<1, 4, EPI_PACKED, false>(p, st))) return rc;
-        r.slabs = g->slabs; r.slab_stride = act; r.S = p.S; r.bias = w.bproj;
+        int S_proj = 1;
+        g->span_begin(WMAR_T_PROJ, st);
+        rc = gemm_split(p, &S_proj, st);
+        g->span_end(st);
+        if (rc) return rc;
+        r.slabs = g->slabs; r.slab_stride = act; r.S = S_proj; r.bias = w.bproj;
+        g->span_begin(WMAR_T_RESID, st);
         hipLaunchKernelGGL(k_resid_stats<false>, dim3(nch * MT), dim3(256), 0, st, r);
+        g->span_end(st);
         if ((rc = launch_status("k_resid_stats"))) return rc;
         // LN2 -> FC1 (+bias, GELU) -> packed hidden
         GemmArgs f = a;
         f.Wp = w.wfc1; f.Xp = g->x; f.bias = w.bfc1; f.KB = KBD; f.NT = 4 * D / 32;
-        f.gamma = w.ln2w; f.beta = w.ln2b; f.out_packed = g->hbuf; f.slab_stride = 0;
-        if ((rc = gemm_dispatch<EPI_GELU, true>(f, false, st))) return rc;
+        f.out_packed = g->hbuf; f.slab_stride = 0;
+        g->span_begin(WMAR_T_FC1, st);
+        rc = gemm_dispatch<EPI_GELU, true>(f, false, st);
+        g->span_end(st);
+        if (rc) return rc;
         // FC2 (split-K partial slabs)
         GemmArgs q = a;
         q.Wp = w.wfc2; q.Xp = g->hbuf; q.bias = nullptr; q.KB = KBF; q.NT = D / 32;
         q.out_packed = g->slabs; q.slab_stride = act;
-        q.S = pick_split(q.NT, MT, q.KB, 4);
-        if ((rc = launch_gemm<1, 4, EPI_PACKED, false>(q, st))) return rc;
-        S_prev = q.S;
+        g->span_begin(WMAR_T_FC2, st);
+        rc = gemm_split(q, &S_prev, st);
+        g->span_end(st);
+        if (rc) return rc;
         bias_prev = w.bfc2;
     }
     // ln_f -> head
     GemmArgs hsd{};
     hsd.MT = MT; hsd.B = (int)B; hsd.stats = g->stats; hsd.n_chunks = nch; hsd.K = D;
-    hsd.Wp = g->whead; hsd.Xp = g->x; hsd.bias = nullptr; hsd.KB = KBD; hsd.NT = g->V / 32;
-    hsd.gamma = g->lnfw; hsd.beta = g->lnfb; hsd.logits = io.logits; hsd.V = g->V;
-    return gemm_dispatch<EPI_LOGITS, true>(hsd, false, st);
+    hsd.Wp = g->whead; hsd.Xp = g->x; hsd.KB = KBD; hsd.NT = g->V / 32;
+    hsd.bias = g->bhead; hsd.logits = io.logits; hsd.V = g->V;
+    g->span_begin(WMAR_T_HEAD, st);
+    rc = gemm_dispatch<EPI_LOGITS, true>(hsd, false, st);
+    g->span_end(st);
+    return rc;
 }
 
 }  // namespace
@@ -582,10 +737,10 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
     if (rc == WMAR_OK) {
         TRY(copy_vec(g, &g->tok_emb, te, (size_t)V * D, st));
         TRY(copy_vec(g, &g->pos_emb, pe, (size_t)cfg->block_size * D, st));
-        TRY(copy_vec(g, &g->lnfw, lfw, D, st));
-        TRY(copy_vec(g, &g->lnfb, lfb, D, st));
         TRY(g->alloc(&g->whead, (size_t)V * D / 4));
-        TRY(pack(g, hw, g->whead, V, D, 0, st));
+        TRY(pack(g, hw, g->whead, V, D, 0, st, lfw));
+        TRY(g->alloc(&g->bhead, (size_t)V));
+        TRY(fold_bias(hw, nullptr, lfb, g->bhead, V, D, st));
     }
     g->layers.resize(L);
     for (int l = 0; l < L && rc == WMAR_OK; ++l) {
@@ -599,29 +754,23 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
         const float *l1w = need(p + "ln1.weight"), *l1b = need(p + "ln1.bias"), *l2w = need(p + "ln2.weight"), *l2b = need(p + "ln2.bias");
         if (rc != WMAR_OK) break;
         TRY(g->alloc(&w.wqkv, (size_t)3 * D * D / 4));
-        TRY(pack(g, qw, w.wqkv, D, D, 0, st));
-        TRY(pack(g, kw, w.wqkv, D, D, D / 32, st));
-        TRY(pack(g, vw, w.wqkv, D, D, 2 * D / 32, st));
+        TRY(pack(g, qw, w.wqkv, D, D, 0, st, l1w));
+        TRY(pack(g, kw, w.wqkv, D, D, D / 32, st, l1w));
+        TRY(pack(g, vw, w.wqkv, D, D, 2 * D / 32, st, l1w));
         TRY(g->alloc(&w.bqkv, (size_t)3 * D));
-        if (rc == WMAR_OK) {
-            hipError_t e1 = hipMemcpyAsync(w.bqkv, qb, D * 4, hipMemcpyDeviceToDevice, st);
-            hipError_t e2 = hipMemcpyAsync(w.bqkv + D, kb, D * 4, hipMemcpyDeviceToDevice, st);
-            hipError_t e3 = hipMemcpyAsync(w.bqkv + 2 * D, vb, D * 4, hipMemcpyDeviceToDevice, st);
-            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { set_error("bias copy failed"); rc = WMAR_EHIP; }
-        }
+        TRY(fold_bias(qw, qb, l1b, w.bqkv, D, D, st));
+        TRY(fold_bias(kw, kb, l1b, w.bqkv + D, D, D, st));
+        TRY(fold_bias(vw, vb, l1b, w.bqkv + 2 * D, D, D, st));
         TRY(g->alloc(&w.wproj, (size_t)D * D / 4));
         TRY(pack(g, pw, w.wproj, D, D, 0, st));
         TRY(copy_vec(g, &w.bproj, pb, D, st));
         TRY(g->alloc(&w.wfc1, (size_t)4 * D * D / 4));
-        TRY(pack(g, f1w, w.wfc1, 4 * D, D, 0, st));
-        TRY(copy_vec(g, &w.bfc1, f1b, 4 * D, st));
+        TRY(pack(g, f1w, w.wfc1, 4 * D, D, 0, st, l2w));
+        TRY(g->alloc(&w.bfc1, (size_t)4 * D));
+        TRY(fold_bias(f1w, f1b, l2b, w.bfc1, 4 * D, D, st));
         TRY(g->alloc(&w.wfc2, (size_t)4 * D * D / 4));
         TRY(pack(g, f2w, w.wfc2, D, 4 * D, 0, st));
         TRY(copy_vec(g, &w.bfc2, f2b, D, st));
-        TRY(copy_vec(g, &w.ln1w, l1w, D, st));
-        TRY(copy_vec(g, &w.ln1b, l1b, D, st));
-        TRY(copy_vec(g, &w.ln2w, l2w, D, st));
-        TRY(copy_vec(g, &w.ln2b, l2b, D, st));
     }
     const size_t Mpad = (size_t)g->MTmax * 32;
     TRY(g->alloc(&g->x, Mpad * D / 4));
@@ -669,9 +818,13 @@ int wmar_gpt_decode_step(wmar_gpt* g, const int64_t* tok_dev, int64_t B, int32_t
 }
 
 int wmar_gpt_set_timing(wmar_gpt* g, int32_t enabled) { if (!g) return WMAR_EINVAL; g->timing = enabled; return WMAR_OK; }
-int wmar_gpt_get_timing(wmar_gpt* g, double* out5) {
-    if (!g || !out5) return WMAR_EINVAL;
-    for (int i = 0; i < 5; ++i) out5[i] = g->times[i];
+int wmar_gpt_get_timing(wmar_gpt* g, double* total_us, int64_t* calls, double* step_ms) {
+    if (!g) return WMAR_EINVAL;
+    for (int i = 0; i < WMAR_T_NCLASS; ++i) {
+        if (total_us) total_us[i] = g->cls_us[i];
+        if (calls) calls[i] = g->cls_calls[i];
+    }
+    if (step_ms) *step_ms = g->step_ms;
     return WMAR_OK;
 }
 
@@ -715,7 +868,10 @@ int wmar_gpt_generate(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_para
     auto one_step = [&](hipStream_t s) -> int {
         int rc = enqueue_step(g, B, io, s);
         if (rc) return rc;
-        if ((rc = launch_sample_fused(a, s))) return rc;
+        g->span_begin(WMAR_T_SAMPLE, s);
+        rc = launch_sample_fused(a, s);
+        g->span_end(s);
+        if (rc) return rc;
         hipLaunchKernelGGL(k_advance3, dim3(1), dim3(1), 0, s, g->pos_dev);
         return launch_status("k_advance3");
     };
@@ -745,15 +901,19 @@ int wmar_gpt_generate(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_para
             return WMAR_EHIP;
         }
     } else {
-        for (int n = 0; n < steps; ++n)
-            if (int rc = one_step(st)) return rc;
+        g->span_on = g->timing != 0;
+        int rc = WMAR_OK;
+        for (int n = 0; n < steps && rc == WMAR_OK; ++n) rc = one_step(st);
+        g->span_on = false;
+        if (rc) return rc;
         if (g->timing) WMAR_HIP_CHECK(hipEventRecord(g->ev1, st));
         WMAR_HIP_CHECK(hipStreamSynchronize(st));
+        if (g->timing) g->span_collect();
     }
     if (g->timing) {
         float ms = 0;
         WMAR_HIP_CHECK(hipEventElapsedTime(&ms, g->ev0, g->ev1));
-        g->times[4] = ms / steps;
+        g->step_ms = ms / steps;
     }
     return WMAR_OK;
 }

@@ -1,0 +1,886 @@
+// Taming VQGAN encoder / decoder / quantizer for gfx950 (fp32, exact-f32 MFMA).
+//
+// Reference: deps/taming/modules/diffusionmodules/model.py:30-193 (Normalize, Upsample,
+// Downsample, ResnetBlock, AttnBlock), :343-538 (Encoder, Decoder);
+// deps/taming/models/vqgan.py:64-73 (encode / decode); deps/taming/modules/vqvae/quantize.py:272-331.
+//
+// Data layout in HBM: every activation is NHWC fp32 ([B][H][W][C], channels padded to a
+// multiple of 8), so a pixel's channel vector is one contiguous run and the 3x3 taps are
+// plain row offsets.  Conv weights [Cout][Cin][kh][kw] are repacked once into
+// MFMA-fragment order Wp[cout_tile][tap][cin_block][lane][4] (A operand of
+// v_mfma_f32_32x32x2_f32: lane = (cout%32) + 32*((cin%8)/4)).
+//
+// conv3x3 / conv1x1 = implicit GEMM, D[cout][pixel] += W[cout][tap,cin] * X[pixel+tap][cin]:
+// a workgroup owns an 8x8 pixel tile and up to 4 cout tiles; the input patch (tile + halo)
+// for 32 input channels at a time is staged through LDS (coalesced rows in, 16-byte
+// fragment reads out), each wave owns one cout tile and both 32-pixel halves.
+// Nearest x2 upsampling (Upsample.forward) and the asymmetric-pad stride-2 downsample
+// (Downsample.forward) are folded into the patch gather; bias and the residual add are
+// folded into the epilogue.  GroupNorm(32, eps 1e-6)+swish is a statistics pass
+// (fp64 partial sums, fixed order) plus an elementwise pass.
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace wmar {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// ------------------------------------------------------------------------ packing
+// W [Cout][Cin][ks][ks] -> Wp[ct][tap][kb][lane] float4;  cout/cin padded with zeros.
+__global__ void k_pack_conv(const float* __restrict__ W, float4* __restrict__ Wp, int Cout, int Cin, int ks,
+                            int CT, int KBc) {
+    const int T = ks * ks;
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)CT * T * KBc * 64;
+    if (idx >= total) return;
+    int lane = (int)(idx & 63);
+    long long r = idx >> 6;
+    int kb = (int)(r % KBc); r /= KBc;
+    int tap = (int)(r % T);
+    int ct = (int)(r / T);
+    int co = ct * 32 + (lane & 31);
+    int ci0 = kb * 8 + 4 * (lane >> 5);
+    float v[4];
+    for (int i = 0; i < 4; ++i) {
+        int ci = ci0 + i;
+        v[i] = (co < Cout && ci < Cin) ? W[((long long)co * Cin + ci) * T + tap] : 0.f;
+    }
+    Wp[idx] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+__global__ void k_pad_vec(const float* __restrict__ src, float* __restrict__ dst, int n, int npad) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npad) dst[i] = i < n ? src[i] : 0.f;
+}
+
+// ------------------------------------------------------------------------ conv
+struct ConvArgs {
+    const float* in;     // NHWC [B][Hs][Ws][Cin]  (Hs,Ws = stored size; the conv sees 2x that when up=1)
+    const float4* wp;
+    const float* bias;   // [CT*32]
+    const float* res;    // nullable NHWC [B][Ho][Wo][Cout_s]
+    float* out;          // NHWC [B][Ho][Wo][Cout_s]
+    int Hs, Ws, Cin;     // Cin: stored (padded) input channels, multiple of 8
+    int Ho, Wo, Cout_s;  // Cout_s: stored output channels (multiple of 8, >= real cout)
+    int CT, KBc;         // cout tiles of 32; cin blocks of 8
+    int ks, stride, up, pad;  // pad = leading pad (1 for 3x3 stride 1, 0 otherwise)
+    int tiles_x, tiles_y;     // 8x8 output tiles per image
+};
+
+constexpr int CONV_CCH = 32;          // input channels staged per LDS round
+constexpr int CONV_PSTRIDE = 36;      // floats per staged pixel (32 + 4 pad: spreads LDS banks)
+
+// COT = cout tiles (= waves) per workgroup.
+template <int COT>
+__global__ __launch_bounds__(COT * 64) void k_conv(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float patch[];  // [PH*PW][CONV_PSTRIDE]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int bid = blockIdx.x;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+    const int cgroups = (a.CT + COT - 1) / COT;
+    const int cg = bid % cgroups;
+    const int b = bid / cgroups;
+    const int ct = cg * COT + w;
+    const bool active = ct < a.CT;
+    const int T = a.ks * a.ks;
+    const int PW = 7 * a.stride + a.ks, PH = PW;
+    const int oy0 = ty * 8, ox0 = tx * 8;
+    const int iy0 = oy0 * a.stride - a.pad, ix0 = ox0 * a.stride - a.pad;
+    const int Hc = a.up ? a.Hs * 2 : a.Hs, Wc = a.up ? a.Ws * 2 : a.Ws;  // size the conv sees
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const int j = lane & 31, half = lane >> 5;
+    // pixel of lane j in pixel-tile p: row = p*4 + j/8, col = j%8
+    const int prow = j >> 3, pcol = j & 7;
+    const float* inb = a.in + (long long)b * a.Hs * a.Ws * a.Cin;
+
+    for (int c0 = 0; c0 < a.Cin; c0 += CONV_CCH) {
+        const int cch = min(CONV_CCH, a.Cin - c0);   // multiple of 8
+        const int q4 = cch >> 2;                     // float4s per pixel this round
+        __syncthreads();
+        for (int e = threadIdx.x; e < PH * PW * q4; e += COT * 64) {
+            const int pix = e / q4, qq = e - pix * q4;
+            const int py = pix / PW, px = pix - py * PW;
+            int y = iy0 + py, x = ix0 + px;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y >= 0 && y < Hc && x >= 0 && x < Wc) {
+                if (a.up) { y >>= 1; x >>= 1; }
+                v = *(const float4*)(inb + ((long long)y * a.Ws + x) * a.Cin + c0 + qq * 4);
+            }
+            *(float4*)(patch + pix * CONV_PSTRIDE + qq * 4) = v;
+        }
+        __syncthreads();
+        if (active) {
+            const int nkb = cch >> 3;
+            const float4* wbase = a.wp + ((long long)ct * T * a.KBc + (c0 >> 3)) * 64 + lane;
+            for (int tap = 0; tap < T; ++tap) {
+                const int dy = tap / a.ks, dx = tap - dy * a.ks;
+                const float4* wt = wbase + (long long)tap * a.KBc * 64;
+                const float* p0 = patch + (((prow)*a.stride + dy) * PW + pcol * a.stride + dx) * CONV_PSTRIDE + half * 4;
+                const float* p1 = p0 + 4 * a.stride * PW * CONV_PSTRIDE;
+#pragma unroll 4
+                for (int kb = 0; kb < nkb; ++kb) {
+                    const float4 wv = wt[kb * 64];
+                    const float4 x0 = *(const float4*)(p0 + kb * 8);
+                    const float4 x1 = *(const float4*)(p1 + kb * 8);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, x0.x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, x1.x, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, x0.y, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, x1.y, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, x0.z, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, x1.z, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, x0.w, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, x1.w, acc[1], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!active) return;
+    // epilogue: lane holds pixel j of each half-tile and couts ct*32 + 8g + 4*half + {0..3}
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int oy = oy0 + p * 4 + prow, ox = ox0 + pcol;
+        const long long pix = ((long long)b * a.Ho + oy) * a.Wo + ox;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = ct * 32 + g * 8 + half * 4;
+            if (co >= a.Cout_s) continue;
+            const float4 bb = *(const float4*)(a.bias + co);
+            float4 o = make_float4(acc[p][g * 4 + 0] + bb.x, acc[p][g * 4 + 1] + bb.y, acc[p][g * 4 + 2] + bb.z,
+                                   acc[p][g * 4 + 3] + bb.w);
+            if (a.res) {
+                const float4 rr = *(const float4*)(a.res + pix * a.Cout_s + co);
+                o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+            }
+            *(float4*)(a.out + pix * a.Cout_s + co) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------ GroupNorm
+// pass 1: per (image, pixel chunk) partial (sum, sumsq) of every group, fp64.
+struct GnArgs {
+    const float* x;   // NHWC [B][HW][C]
+    float* y;
+    double* partial;  // [B][nchunk][32][2]
+    const float* gamma; const float* beta;
+    int HW, C, nchunk, swish;
+};
+
+__global__ __launch_bounds__(256) void k_gn_partial(GnArgs a) {
+    __shared__ double red[256][2];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int q4 = a.C >> 2;                 // float4 per pixel
+    const int cpg = a.C / 32;                // channels per group (4, 8, 16 or 1/2 in tiny configs)
+    const int p0 = (int)((long long)chunk * a.HW / a.nchunk), p1 = (int)((long long)(chunk + 1) * a.HW / a.nchunk);
+    // thread t owns float4 column (t % q4) and walks pixels p0 + t/q4, + 256/q4 ...  (q4 divides 256 for C in {32..1024})
+    const int col = threadIdx.x % q4, prow = threadIdx.x / q4, pstep = 256 / q4;
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    const float* xb = a.x + (long long)b * a.HW * a.C;
+    if (prow < pstep)
+        for (int p = p0 + prow; p < p1; p += pstep) {
+            float4 v = *(const float4*)(xb + (long long)p * a.C + col * 4);
+            s[0] += v.x; ss[0] += (double)v.x * v.x;
+            s[1] += v.y; ss[1] += (double)v.y * v.y;
+            s[2] += v.z; ss[2] += (double)v.z * v.z;
+            s[3] += v.w; ss[3] += (double)v.w * v.w;
+        }
+    // fold the 4 channels of this thread into their groups, then reduce threads in fixed order
+    __shared__ double acc[32][2];
+    if (threadIdx.x < 32) { acc[threadIdx.x][0] = 0; acc[threadIdx.x][1] = 0; }
+    __syncthreads();
+    // deterministic: one pass per pixel-row slot, serialised by barrier-free ownership:
+    // write per-thread values to LDS, then 32 threads each sum their group's contributors in order.
+    __shared__ double tmp[256][4][2];
+    for (int i = 0; i < 4; ++i) { tmp[threadIdx.x][i][0] = s[i]; tmp[threadIdx.x][i][1] = ss[i]; }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int g = threadIdx.x;
+        double ts = 0, tss = 0;
+        for (int t = 0; t < 256; ++t) {
+            if (t / q4 >= pstep) break;
+            const int c = (t % q4) * 4;
+            for (int i = 0; i < 4; ++i)
+                if ((c + i) / cpg == g) { ts += tmp[t][i][0]; tss += tmp[t][i][1]; }
+        }
+        double* o = a.partial + (((long long)b * a.nchunk + chunk) * 32 + g) * 2;
+        o[0] = ts; o[1] = tss;
+    }
+}
+
+// pass 2: y = swish?( (x - mean) * rstd * gamma + beta )
+__global__ __launch_bounds__(256) void k_gn_apply(GnArgs a) {
+    __shared__ float s_mean[32], s_rstd[32];
+    const int b = blockIdx.y;
+    if (threadIdx.x < 32) {
+        double ts = 0, tss = 0;
+        for (int c = 0; c < a.nchunk; ++c) {
+            const double* p = a.partial + (((long long)b * a.nchunk + c) * 32 + threadIdx.x) * 2;
+            ts += p[0]; tss += p[1];
+        }
+        const double n = (double)a.HW * (a.C / 32);
+        const double mean = ts / n;
+        const double var = tss / n - mean * mean;
+        s_mean[threadIdx.x] = (float)mean;
+        s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + 1e-6));
+    }
+    __syncthreads();
+    const int q4 = a.C >> 2, cpg = a.C / 32;
+    const long long total = (long long)a.HW * q4;
+    const float* xb = a.x + (long long)b * a.HW * a.C;
+    float* yb = a.y + (long long)b * a.HW * a.C;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e % q4) * 4;
+        float4 v = *(const float4*)(xb + e * 4);
+        float4 g = *(const float4*)(a.gamma + c), bt = *(const float4*)(a.beta + c);
+        float r[4] = {v.x, v.y, v.z, v.w};
+        const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int grp = (c + i) / cpg;
+            float h = (r[i] - s_mean[grp]) * s_rstd[grp] * gg[i] + bb[i];
+            if (a.swish) h = h / (1.0f + __expf(-h));
+            r[i] = h;
+        }
+        *(float4*)(yb + e * 4) = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+// ------------------------------------------------------------------------ attention (single head)
+// q,k,v: NHWC [B][N][C] (N = H*W tokens).  scores[b][i][j] = softmax_j( q_i . k_j * C^-0.5 );
+// o[b][i][:] = sum_j scores[i][j] v[j][:]     (AttnBlock.forward, model.py:176-189)
+__global__ __launch_bounds__(256) void k_attn_scores(const float* __restrict__ q, const float* __restrict__ k,
+                                                     float* __restrict__ sc, int N, int C, float scale) {
+    // one workgroup per (b, query i): 256 threads cover keys j
+    extern __shared__ float qs[];  // [C]
+    __shared__ float red[4];
+    const int b = blockIdx.y, i = blockIdx.x;
+    const float* qi = q + ((long long)b * N + i) * C;
+    for (int c = threadIdx.x; c < C; c += 256) qs[c] = qi[c];
+    __syncthreads();
+    float* row = sc + ((long long)b * N + i) * N;
+    float mx = -INFINITY;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        const float* kj = k + ((long long)b * N + j) * C;
+        float s = 0.f;
+        for (int c = 0; c < C; c += 4) {
+            float4 kv = *(const float4*)(kj + c);
+            s += qs[c] * kv.x + qs[c + 1] * kv.y + qs[c + 2] * kv.z + qs[c + 3] * kv.w;
+        }
+        s *= scale;
+        row[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        float e = __expf(row[j] - mx);
+        row[j] = e;
+        sum += e;
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    sum = red[0] + red[1] + red[2] + red[3];
+    const float inv = 1.0f / sum;
+    for (int j = threadIdx.x; j < N; j += 256) row[j] *= inv;
+}
+
+__global__ __launch_bounds__(256) void k_attn_pv(const float* __restrict__ sc, const float* __restrict__ v,
+                                                 float* __restrict__ o, int N, int C) {
+    // one workgroup per (b, query i); threads cover channels
+    extern __shared__ float ps[];  // [N]
+    const int b = blockIdx.y, i = blockIdx.x;
+    const float* row = sc + ((long long)b * N + i) * N;
+    for (int j = threadIdx.x; j < N; j += 256) ps[j] = row[j];
+    __syncthreads();
+    for (int c = threadIdx.x * 4; c < C; c += 1024) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < N; ++j) {
+            float4 vv = *(const float4*)(v + ((long long)b * N + j) * C + c);
+            const float p = ps[j];
+            acc.x += p * vv.x; acc.y += p * vv.y; acc.z += p * vv.z; acc.w += p * vv.w;
+        }
+        *(float4*)(o + ((long long)b * N + i) * C + c) = acc;
+    }
+}
+
+// ------------------------------------------------------------------------ quantizer
+__global__ void k_codebook_gather(const long long* __restrict__ codes, const float* __restrict__ emb,
+                                  float* __restrict__ z, long long npix, int E, int n_embed) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over npix * E/4
+    const int q4 = E >> 2;
+    if (idx >= npix * q4) return;
+    long long p = idx / q4;
+    int c = (int)(idx % q4) * 4;
+    long long code = codes[p];
+    if (code < 0) code = 0;
+    if (code >= n_embed) code = n_embed - 1;
+    *(float4*)(z + p * E + c) = *(const float4*)(emb + code * E + c);
+}
+
+__global__ __launch_bounds__(64) void k_row_sqnorm(const float* __restrict__ x, float* __restrict__ out, int E) {
+    // out[r] = sum_c x[r][c]^2, sequential-pairwise like a plain fp32 reduction
+    const long long r = blockIdx.x;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < E; c += 64) { float v = x[r * E + c]; s += v * v; }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) out[r] = s;
+}
+
+// argmin_n ( |z|^2 + |e_n|^2 - 2 z.e_n ), first minimum (VectorQuantizer2.forward, quantize.py:277-285).
+// One workgroup = 64 pixels (2 MFMA column tiles) x all codes; z rows live in LDS for the whole
+// sweep; each of the 4 waves takes every 4th 32-code tile and keeps a running (min, index).
+struct VqArgs {
+    const float* z;       // [P][E]
+    const float4* ep;     // packed codebook [NT][KB][64]
+    const float* enorm;   // [n_embed]
+    const float* znorm;   // [P]
+    long long* codes;     // [P]
+    long long P;
+    int E, n_embed;
+};
+
+__global__ __launch_bounds__(256) void k_vq_argmin(VqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float zs[];  // [64][E+4]
+    __shared__ float bestv[4][64];
+    __shared__ int besti[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long p0 = (long long)blockIdx.x * 64;
+    const int ZS = a.E + 4;
+    for (int e = threadIdx.x; e < 64 * (a.E >> 2); e += 256) {
+        const int r = e / (a.E >> 2), c = (e % (a.E >> 2)) * 4;
+        float4 v = (p0 + r < a.P) ? *(const float4*)(a.z + (p0 + r) * a.E + c) : make_float4(0, 0, 0, 0);
+        *(float4*)(zs + r * ZS + c) = v;
+    }
+    __syncthreads();
+    const int j = lane & 31, half = lane >> 5;
+    const int KB = a.E >> 3, NT = a.n_embed >> 5;
+    float zn[2];
+    zn[0] = (p0 + j < a.P) ? a.znorm[p0 + j] : 0.f;
+    zn[1] = (p0 + 32 + j < a.P) ? a.znorm[p0 + 32 + j] : 0.f;
+    float bv[2] = {INFINITY, INFINITY};
+    int bi[2] = {0, 0};
+    for (int nt = w; nt < NT; nt += 4) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        const float4* wt = a.ep + (long long)nt * KB * 64 + lane;
+#pragma unroll 4
+        for (int kb = 0; kb < KB; ++kb) {
+            const float4 wv = wt[kb * 64];
+            const float4 x0 = *(const float4*)(zs + j * ZS + kb * 8 + half * 4);
+            const float4 x1 = *(const float4*)(zs + (32 + j) * ZS + kb * 8 + half * 4);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, x0.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, x1.x, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, x0.y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, x1.y, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, x0.z, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, x1.z, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, x0.w, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, x1.w, acc[1], 0, 0, 0);
+        }
+        // lane holds pixel j (of each half) and codes nt*32 + (r&3) + 8*(r>>2) + 4*half, ascending in r
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float d = (zn[p] + a.enorm[n]) - 2.0f * acc[p][r];
+                if (d < bv[p] || (d == bv[p] && n < bi[p])) { bv[p] = d; bi[p] = n; }
+            }
+    }
+    // combine the two lane halves (same pixel, interleaved code sets), then the 4 waves
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        float ov = __shfl_xor(bv[p], 32);
+        int oi = __shfl_xor(bi[p], 32);
+        if (ov < bv[p] || (ov == bv[p] && oi < bi[p])) { bv[p] = ov; bi[p] = oi; }
+        if (half == 0) { bestv[w][p * 32 + j] = bv[p]; besti[w][p * 32 + j] = bi[p]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float v = bestv[0][threadIdx.x];
+        int i = besti[0][threadIdx.x];
+        for (int ww = 1; ww < 4; ++ww) {
+            float ov = bestv[ww][threadIdx.x];
+            int oi = besti[ww][threadIdx.x];
+            if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+        }
+        if (p0 + threadIdx.x < a.P) a.codes[p0 + threadIdx.x] = i;
+    }
+}
+
+// ------------------------------------------------------------------------ layout conversions
+// NCHW image -> NHWC with channels padded to Cs
+__global__ void k_nchw_to_nhwc(const float* __restrict__ src, float* __restrict__ dst, int C, int HW, int Cs) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over B*HW (grid.y = unused)
+    const long long b = blockIdx.y;
+    if (idx >= HW) return;
+    for (int c = 0; c < Cs; ++c)
+        dst[((long long)b * HW + idx) * Cs + c] = c < C ? src[((long long)b * C + c) * HW + idx] : 0.f;
+}
+
+// NHWC (stored Cs channels) -> NCHW first C channels, clamped to [-1, 1] (taming_wrapper.py:82)
+__global__ void k_nhwc_to_nchw_clamp(const float* __restrict__ src, float* __restrict__ dst, int C, int HW, int Cs) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long b = blockIdx.y;
+    if (idx >= HW) return;
+    for (int c = 0; c < C; ++c) {
+        float v = src[((long long)b * HW + idx) * Cs + c];
+        dst[((long long)b * C + c) * HW + idx] = fminf(fmaxf(v, -1.0f), 1.0f);
+    }
+}
+
+}  // namespace wmar
+
+using namespace wmar;
+
+// ------------------------------------------------------------------------------ engine
+struct ConvW {
+    float4* wp = nullptr;
+    float* bias = nullptr;
+    int cin = 0, cout = 0, cin_s = 0, cout_s = 0, ks = 1, CT = 0, KBc = 0;
+};
+struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
+struct ResW { NormW n1, n2; ConvW c1, c2, nin; bool has_nin = false; };
+struct AttnW { NormW n; ConvW q, k, v, proj; };
+
+struct wmar_vq {
+    wmar_vq_config cfg{};
+    std::vector<void*> allocs;
+    int64_t bytes = 0;
+    int Bmax = 0, S = 0;
+    // decoder
+    ConvW post_quant, d_conv_in, d_conv_out;
+    ResW d_mid1, d_mid2; AttnW d_midattn;
+    std::vector<std::vector<ResW>> d_up;        // [level][block]
+    std::vector<std::vector<AttnW>> d_upattn;   // [level][block]
+    std::vector<ConvW> d_upsample;              // [level]
+    NormW d_norm_out;
+    // encoder
+    ConvW quant, e_conv_in, e_conv_out;
+    ResW e_mid1, e_mid2; AttnW e_midattn;
+    std::vector<std::vector<ResW>> e_down;
+    std::vector<std::vector<AttnW>> e_downattn;
+    std::vector<ConvW> e_downsample;
+    NormW e_norm_out;
+    // quantizer
+    float* emb = nullptr; float4* emb_p = nullptr; float* enorm = nullptr;
+    // workspaces
+    float* buf[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t buf_elems = 0;
+    float *aq = nullptr, *ak = nullptr, *av = nullptr, *ao = nullptr, *asc = nullptr;
+    double* gn_partial = nullptr;
+    float* znorm = nullptr;
+
+    template <typename T>
+    int alloc(T** p, size_t n) {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, (n ? n : 1) * sizeof(T));
+        if (e != hipSuccess) {
+            set_error("hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
+            return WMAR_ENOMEM;
+        }
+        allocs.push_back(q);
+        bytes += (int64_t)(n * sizeof(T));
+        *p = (T*)q;
+        return WMAR_OK;
+    }
+    ~wmar_vq() { for (void* p : allocs) (void)hipFree(p); }
+};
+
+namespace {
+
+constexpr int GN_CHUNKS_MAX = 64;
+inline int pad8(int c) { return (c + 7) & ~7; }
+
+struct Loader {
+    std::map<std::string, const void*> m;
+    wmar_vq* v;
+    hipStream_t st;
+    int rc = WMAR_OK;
+    const float* need(const std::string& k) {
+        auto it = m.find(k);
+        if (it == m.end()) {
+            if (rc == WMAR_OK) { set_error("checkpoint tensor '%s' is missing", k.c_str()); rc = WMAR_EMISSING; }
+            return nullptr;
+        }
+        return (const float*)it->second;
+    }
+    void conv(const std::string& p, int cin, int cout, int ks, ConvW& c) {
+        const float* W = need(p + ".weight");
+        const float* bsrc = need(p + ".bias");
+        if (rc) return;
+        c.cin = cin; c.cout = cout; c.ks = ks; c.cin_s = pad8(cin); c.cout_s = pad8(cout);
+        c.CT = (cout + 31) / 32; c.KBc = c.cin_s / 8;
+        size_t n = (size_t)c.CT * ks * ks * c.KBc * 64;
+        if ((rc = v->alloc(&c.wp, n))) return;
+        hipLaunchKernelGGL(k_pack_conv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, c.wp, cout, cin, ks, c.CT, c.KBc);
+        if ((rc = v->alloc(&c.bias, (size_t)c.CT * 32))) return;
+        hipLaunchKernelGGL(k_pad_vec, dim3((c.CT * 32 + 255) / 256), dim3(256), 0, st, bsrc, c.bias, cout, c.CT * 32);
+        rc = launch_status("k_pack_conv");
+    }
+    void norm(const std::string& p, int C, NormW& n) {
+        const float* g = need(p + ".weight");
+        const float* b = need(p + ".bias");
+        if (rc) return;
+        n.C = C;
+        if ((rc = v->alloc(&n.g, (size_t)C))) return;
+        if ((rc = v->alloc(&n.b, (size_t)C))) return;
+        if (hipMemcpyAsync(n.g, g, C * 4, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(n.b, b, C * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            set_error("norm copy failed"); rc = WMAR_EHIP;
+        }
+    }
+    void res(const std::string& p, int cin, int cout, ResW& r) {
+        norm(p + "norm1", cin, r.n1);
+        conv(p + "conv1", cin, cout, 3, r.c1);
+        norm(p + "norm2", cout, r.n2);
+        conv(p + "conv2", cout, cout, 3, r.c2);
+        r.has_nin = cin != cout;
+        if (r.has_nin) conv(p + "nin_shortcut", cin, cout, 1, r.nin);
+    }
+    void attn(const std::string& p, int c, AttnW& a) {
+        norm(p + "norm", c, a.n);
+        conv(p + "q", c, c, 1, a.q);
+        conv(p + "k", c, c, 1, a.k);
+        conv(p + "v", c, c, 1, a.v);
+        conv(p + "proj_out", c, c, 1, a.proj);
+    }
+};
+
+bool in_attn_res(const wmar_vq_config& c, int res) {
+    for (int i = 0; i < c.n_attn_res; ++i)
+        if (c.attn_resolutions[i] == res) return true;
+    return false;
+}
+
+int run_conv(const ConvW& c, const float* in, float* out, const float* res, int B, int Hs, int Ws, int stride, int up,
+             hipStream_t st) {
+    ConvArgs a{};
+    a.in = in; a.wp = c.wp; a.bias = c.bias; a.res = res; a.out = out;
+    a.Hs = Hs; a.Ws = Ws; a.Cin = c.cin_s;
+    const int Hc = up ? 2 * Hs : Hs, Wc = up ? 2 * Ws : Ws;
+    a.Ho = stride == 2 ? Hc / 2 : Hc; a.Wo = stride == 2 ? Wc / 2 : Wc;
+    a.Cout_s = c.cout_s; a.CT = c.CT; a.KBc = c.KBc; a.ks = c.ks; a.stride = stride; a.up = up;
+    a.pad = (c.ks == 3 && stride == 1) ? 1 : 0;
+    WMAR_REQUIRE(a.Ho % 8 == 0 && a.Wo % 8 == 0, "conv output %dx%d is not a multiple of the 8x8 tile", a.Ho, a.Wo);
+    a.tiles_x = a.Wo / 8; a.tiles_y = a.Ho / 8;
+    const int PW = 7 * stride + c.ks;
+    const size_t lds = (size_t)PW * PW * CONV_PSTRIDE * sizeof(float);
+    const int COT = c.CT >= 4 ? 4 : (c.CT >= 2 ? 2 : 1);
+    const int cgroups = (c.CT + COT - 1) / COT;
+    const unsigned grid = (unsigned)((long long)B * cgroups * a.tiles_x * a.tiles_y);
+    if (COT == 4) hipLaunchKernelGGL(k_conv<4>, dim3(grid), dim3(256), lds, st, a);
+    else if (COT == 2) hipLaunchKernelGGL(k_conv<2>, dim3(grid), dim3(128), lds, st, a);
+    else hipLaunchKernelGGL(k_conv<1>, dim3(grid), dim3(64), lds, st, a);
+    return launch_status("k_conv");
+}
+
+int run_gn(wmar_vq* v, const NormW& n, const float* x, float* y, int B, int HW, int swish, hipStream_t st) {
+    GnArgs a{};
+    a.x = x; a.y = y; a.partial = v->gn_partial; a.gamma = n.g; a.beta = n.b; a.HW = HW; a.C = n.C; a.swish = swish;
+    WMAR_REQUIRE(n.C % 32 == 0 && n.C / 4 <= 256, "GroupNorm channel count %d unsupported (multiple of 32, <= 1024)", n.C);
+    int nchunk = HW / 256;
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > GN_CHUNKS_MAX) nchunk = GN_CHUNKS_MAX;
+    a.nchunk = nchunk;
+    hipLaunchKernelGGL(k_gn_partial, dim3(nchunk, B), dim3(256), 0, st, a);
+    long long total = (long long)HW * (n.C / 4);
+    int gx = (int)((total + 256 * 8 - 1) / (256 * 8));
+    if (gx < 1) gx = 1;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(k_gn_apply, dim3(gx, B), dim3(256), 0, st, a);
+    return launch_status("k_gn");
+}
+
+// x (buf X) -> result left in returned buffer index; uses the 4 rotating buffers
+struct Bufs {
+    wmar_vq* v;
+    int x = 0;          // index of the current activation
+    float* X() { return v->buf[x]; }
+    float* other(int k) { return v->buf[(x + k) & 3]; }
+    void advance(int k) { x = (x + k) & 3; }
+};
+
+int run_res(wmar_vq* v, const ResW& r, Bufs& bf, int B, int H, int W, hipStream_t st) {
+    int rc;
+    float *X = bf.X(), *A = bf.other(1), *T = bf.other(2), *C = bf.other(3);
+    if ((rc = run_gn(v, r.n1, X, A, B, H * W, 1, st))) return rc;
+    if ((rc = run_conv(r.c1, A, T, nullptr, B, H, W, 1, 0, st))) return rc;
+    if ((rc = run_gn(v, r.n2, T, A, B, H * W, 1, st))) return rc;
+    const float* shortcut = X;
+    if (r.has_nin) {
+        if ((rc = run_conv(r.nin, X, C, nullptr, B, H, W, 1, 0, st))) return rc;
+        shortcut = C;
+    }
+    if ((rc = run_conv(r.c2, A, T, shortcut, B, H, W, 1, 0, st))) return rc;
+    bf.advance(2);
+    return WMAR_OK;
+}
+
+int run_attn(wmar_vq* v, const AttnW& w, Bufs& bf, int B, int H, int W, hipStream_t st) {
+    int rc;
+    const int N = H * W, C = w.n.C;
+    float *X = bf.X(), *A = bf.other(1), *T = bf.other(2);
+    if ((rc = run_gn(v, w.n, X, A, B, N, 0, st))) return rc;
+    if ((rc = run_conv(w.q, A, v->aq, nullptr, B, H, W, 1, 0, st))) return rc;
+    if ((rc = run_conv(w.k, A, v->ak, nullptr, B, H, W, 1, 0, st))) return rc;
+    if ((rc = run_conv(w.v, A, v->av, nullptr, B, H, W, 1, 0, st))) return rc;
+    const float scale = 1.0f / sqrtf((float)C);   // int(c)**(-0.5)
+    hipLaunchKernelGGL(k_attn_scores, dim3(N, B), dim3(256), (size_t)C * 4, st, v->aq, v->ak, v->asc, N, C, scale);
+    hipLaunchKernelGGL(k_attn_pv, dim3(N, B), dim3(256), (size_t)N * 4, st, v->asc, v->av, v->ao, N, C);
+    if ((rc = launch_status("k_attn"))) return rc;
+    if ((rc = run_conv(w.proj, v->ao, T, X, B, H, W, 1, 0, st))) return rc;
+    bf.advance(2);
+    return WMAR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wmar_vq_create(const wmar_vq_config* cfg, const char* const* names, const void* const* tensors_dev,
+                   int32_t n_tensors, void* stream, wmar_vq** out) {
+    WMAR_REQUIRE(cfg && names && tensors_dev && out, "vq_create: null argument");
+    WMAR_REQUIRE(cfg->n_levels >= 1 && cfg->n_levels <= 8, "vq_create: bad ch_mult length");
+    WMAR_REQUIRE(cfg->max_batch >= 1, "vq_create: max_batch");
+    WMAR_REQUIRE(cfg->embed_dim % 8 == 0 && cfg->n_embed % 32 == 0, "embed_dim %% 8 and n_embed %% 32 must be 0");
+    WMAR_REQUIRE(cfg->ch % 32 == 0, "ch must be a multiple of 32 (GroupNorm has 32 groups)");
+    const int L = cfg->n_levels;
+    const int S = cfg->resolution >> (L - 1);
+    WMAR_REQUIRE(S >= 8 && S % 8 == 0 && (S << (L - 1)) == cfg->resolution, "latent size %d must be a multiple of 8", S);
+    auto* v = new wmar_vq();
+    v->cfg = *cfg; v->Bmax = cfg->max_batch; v->S = S;
+    Loader ld;
+    ld.v = v; ld.st = (hipStream_t)stream;
+    for (int i = 0; i < n_tensors; ++i) ld.m[names[i]] = tensors_dev[i];
+    const int ch = cfg->ch, z = cfg->z_channels, E = cfg->embed_dim;
+
+    // ---- decoder (model.py:437-505)
+    int block_in = ch * cfg->ch_mult[L - 1];
+    int res = S;
+    ld.conv("post_quant_conv", E, z, 1, v->post_quant);
+    ld.conv("decoder.conv_in", z, block_in, 3, v->d_conv_in);
+    ld.res("decoder.mid.block_1.", block_in, block_in, v->d_mid1);
+    ld.attn("decoder.mid.attn_1.", block_in, v->d_midattn);
+    ld.res("decoder.mid.block_2.", block_in, block_in, v->d_mid2);
+    v->d_up.resize(L); v->d_upattn.resize(L); v->d_upsample.resize(L);
+    for (int lvl = L - 1; lvl >= 0; --lvl) {
+        const int block_out = ch * cfg->ch_mult[lvl];
+        v->d_up[lvl].resize(cfg->num_res_blocks + 1);
+        for (int b = 0; b <= cfg->num_res_blocks; ++b) {
+            const std::string p = "decoder.up." + std::to_string(lvl) + ".";
+            ld.res(p + "block." + std::to_string(b) + ".", block_in, block_out, v->d_up[lvl][b]);
+            block_in = block_out;
+            if (in_attn_res(*cfg, res)) {
+                v->d_upattn[lvl].emplace_back();
+                ld.attn(p + "attn." + std::to_string(b) + ".", block_in, v->d_upattn[lvl].back());
+            }
+        }
+        if (lvl != 0) {
+            ld.conv("decoder.up." + std::to_string(lvl) + ".upsample.conv", block_in, block_in, 3, v->d_upsample[lvl]);
+            res *= 2;
+        }
+    }
+    ld.norm("decoder.norm_out", block_in, v->d_norm_out);
+    ld.conv("decoder.conv_out", block_in, cfg->out_ch, 3, v->d_conv_out);
+
+    // ---- encoder (model.py:343-404)
+    ld.conv("encoder.conv_in", cfg->in_channels, ch, 3, v->e_conv_in);
+    v->e_down.resize(L); v->e_downattn.resize(L); v->e_downsample.resize(L);
+    res = cfg->resolution;
+    block_in = ch;
+    for (int lvl = 0; lvl < L; ++lvl) {
+        block_in = ch * (lvl == 0 ? 1 : cfg->ch_mult[lvl - 1]);
+        const int block_out = ch * cfg->ch_mult[lvl];
+        v->e_down[lvl].resize(cfg->num_res_blocks);
+        for (int b = 0; b < cfg->num_res_blocks; ++b) {
+            const std::string p = "encoder.down." + std::to_string(lvl) + ".";
+            ld.res(p + "block." + std::to_string(b) + ".", block_in, block_out, v->e_down[lvl][b]);
+            block_in = block_out;
+            if (in_attn_res(*cfg, res)) {
+                v->e_downattn[lvl].emplace_back();
+                ld.attn(p + "attn." + std::to_string(b) + ".", block_in, v->e_downattn[lvl].back());
+            }
+        }
+        if (lvl != L - 1) {
+            ld.conv("encoder.down." + std::to_string(lvl) + ".downsample.conv", block_in, block_in, 3, v->e_downsample[lvl]);
+            res /= 2;
+        }
+    }
+    ld.res("encoder.mid.block_1.", block_in, block_in, v->e_mid1);
+    ld.attn("encoder.mid.attn_1.", block_in, v->e_midattn);
+    ld.res("encoder.mid.block_2.", block_in, block_in, v->e_mid2);
+    ld.norm("encoder.norm_out", block_in, v->e_norm_out);
+    ld.conv("encoder.conv_out", block_in, z, 3, v->e_conv_out);
+    ld.conv("quant_conv", z, E, 1, v->quant);
+
+    // ---- quantizer
+    int rc = ld.rc;
+    const float* emb = ld.need("quantize.embedding.weight");
+    rc = ld.rc;
+    hipStream_t st = (hipStream_t)stream;
+#define TRY(x) do { if (rc == WMAR_OK) rc = (x); } while (0)
+    TRY(v->alloc(&v->emb, (size_t)cfg->n_embed * E));
+    if (rc == WMAR_OK && hipMemcpyAsync(v->emb, emb, (size_t)cfg->n_embed * E * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        set_error("embedding copy failed"); rc = WMAR_EHIP;
+    }
+    TRY(v->alloc(&v->emb_p, (size_t)cfg->n_embed * E / 4));
+    TRY(v->alloc(&v->enorm, (size_t)cfg->n_embed));
+    if (rc == WMAR_OK) {
+        // the codebook as a 1x1 "conv" weight [n_embed][E]: same fragment packing
+        size_t n = (size_t)(cfg->n_embed / 32) * (E / 8) * 64;
+        hipLaunchKernelGGL(k_pack_conv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, emb, v->emb_p, cfg->n_embed, E, 1,
+                           cfg->n_embed / 32, E / 8);
+        hipLaunchKernelGGL(k_row_sqnorm, dim3(cfg->n_embed), dim3(64), 0, st, v->emb, v->enorm, E);
+        rc = launch_status("codebook pack");
+    }
+    // ---- workspaces: the largest activation any layer produces
+    size_t maxel = 0;
+    {
+        int r = cfg->resolution;
+        for (int lvl = 0; lvl < L; ++lvl) {
+            int cmax = ch * cfg->ch_mult[lvl];
+            if (lvl > 0 && ch * cfg->ch_mult[lvl - 1] > cmax) cmax = ch * cfg->ch_mult[lvl - 1];
+            if (lvl + 1 < L && ch * cfg->ch_mult[lvl + 1] > cmax) cmax = ch * cfg->ch_mult[lvl + 1];
+            size_t el = (size_t)r * r * pad8(cmax);
+            if (el > maxel) maxel = el;
+            r /= 2;
+        }
+        size_t el0 = (size_t)cfg->resolution * cfg->resolution * pad8(cfg->in_channels > cfg->out_ch ? cfg->in_channels : cfg->out_ch);
+        if (el0 > maxel) maxel = el0;
+    }
+    v->buf_elems = maxel * v->Bmax;
+    for (int i = 0; i < 4; ++i) TRY(v->alloc(&v->buf[i], v->buf_elems));
+    const int cattn = ch * cfg->ch_mult[L - 1];
+    // attention scratch sized for the largest attention resolution
+    int amax = 0;
+    for (int i = 0; i < cfg->n_attn_res; ++i) amax = cfg->attn_resolutions[i] > amax ? cfg->attn_resolutions[i] : amax;
+    if (amax < S) amax = S;
+    const size_t ntok = (size_t)amax * amax;
+    int cam = 0;
+    for (int lvl = 0; lvl < L; ++lvl) cam = ch * cfg->ch_mult[lvl] > cam ? ch * cfg->ch_mult[lvl] : cam;
+    (void)cattn;
+    TRY(v->alloc(&v->aq, (size_t)v->Bmax * ntok * cam));
+    TRY(v->alloc(&v->ak, (size_t)v->Bmax * ntok * cam));
+    TRY(v->alloc(&v->av, (size_t)v->Bmax * ntok * cam));
+    TRY(v->alloc(&v->ao, (size_t)v->Bmax * ntok * cam));
+    TRY(v->alloc(&v->asc, (size_t)v->Bmax * ntok * ntok));
+    TRY(v->alloc(&v->gn_partial, (size_t)v->Bmax * GN_CHUNKS_MAX * 32 * 2));
+    TRY(v->alloc(&v->znorm, (size_t)v->Bmax * S * S));
+    if (rc == WMAR_OK && hipStreamSynchronize(st) != hipSuccess) { set_error("vq_create: sync failed"); rc = WMAR_EHIP; }
+#undef TRY
+    if (rc != WMAR_OK) { delete v; return rc; }
+    *out = v;
+    return WMAR_OK;
+}
+
+void wmar_vq_destroy(wmar_vq* v) { delete v; }
+int64_t wmar_vq_device_bytes(const wmar_vq* v) { return v ? v->bytes : 0; }
+
+int wmar_vq_decode(wmar_vq* v, const int64_t* codes_dev, int64_t B, float* images_dev, void* stream) {
+    WMAR_REQUIRE(v && codes_dev && images_dev, "vq_decode: null argument");
+    WMAR_REQUIRE(B >= 1 && B <= v->Bmax, "vq_decode: batch %lld outside 1..%d", (long long)B, v->Bmax);
+    hipStream_t st = (hipStream_t)stream;
+    const wmar_vq_config& c = v->cfg;
+    const int L = c.n_levels, S = v->S, E = c.embed_dim;
+    int rc;
+    Bufs bf{v};
+    // get_codebook_entry (quantize.py:316-331): z_q in NHWC is just the gathered rows
+    const long long npix = (long long)B * S * S;
+    hipLaunchKernelGGL(k_codebook_gather, dim3((unsigned)((npix * (E / 4) + 255) / 256)), dim3(256), 0, st,
+                       (const long long*)codes_dev, v->emb, bf.X(), npix, E, c.n_embed);
+    if ((rc = launch_status("k_codebook_gather"))) return rc;
+    if ((rc = run_conv(v->post_quant, bf.X(), bf.other(1), nullptr, (int)B, S, S, 1, 0, st))) return rc;
+    bf.advance(1);
+    if ((rc = run_conv(v->d_conv_in, bf.X(), bf.other(1), nullptr, (int)B, S, S, 1, 0, st))) return rc;
+    bf.advance(1);
+    int H = S;
+    if ((rc = run_res(v, v->d_mid1, bf, (int)B, H, H, st))) return rc;
+    if ((rc = run_attn(v, v->d_midattn, bf, (int)B, H, H, st))) return rc;
+    if ((rc = run_res(v, v->d_mid2, bf, (int)B, H, H, st))) return rc;
+    for (int lvl = L - 1; lvl >= 0; --lvl) {
+        for (int b = 0; b <= c.num_res_blocks; ++b) {
+            if ((rc = run_res(v, v->d_up[lvl][b], bf, (int)B, H, H, st))) return rc;
+            if (!v->d_upattn[lvl].empty())
+                if ((rc = run_attn(v, v->d_upattn[lvl][b], bf, (int)B, H, H, st))) return rc;
+        }
+        if (lvl != 0) {
+            if ((rc = run_conv(v->d_upsample[lvl], bf.X(), bf.other(1), nullptr, (int)B, H, H, 1, 1, st))) return rc;
+            bf.advance(1);
+            H *= 2;
+        }
+    }
+    if ((rc = run_gn(v, v->d_norm_out, bf.X(), bf.other(1), (int)B, H * H, 1, st))) return rc;
+    if ((rc = run_conv(v->d_conv_out, bf.other(1), bf.other(2), nullptr, (int)B, H, H, 1, 0, st))) return rc;
+    const int HW = H * H;
+    hipLaunchKernelGGL(k_nhwc_to_nchw_clamp, dim3((HW + 255) / 256, (unsigned)B), dim3(256), 0, st, bf.other(2), images_dev,
+                       c.out_ch, HW, v->d_conv_out.cout_s);
+    return launch_status("k_nhwc_to_nchw_clamp");
+}
+
+int wmar_vq_encode(wmar_vq* v, const float* images_dev, int64_t B, int64_t* codes_dev, float* prequant_dev,
+                   void* stream) {
+    WMAR_REQUIRE(v && images_dev && codes_dev, "vq_encode: null argument");
+    WMAR_REQUIRE(B >= 1 && B <= v->Bmax, "vq_encode: batch %lld outside 1..%d", (long long)B, v->Bmax);
+    hipStream_t st = (hipStream_t)stream;
+    const wmar_vq_config& c = v->cfg;
+    const int L = c.n_levels, S = v->S, E = c.embed_dim;
+    int rc;
+    Bufs bf{v};
+    int H = c.resolution;
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3((H * H + 255) / 256, (unsigned)B), dim3(256), 0, st, images_dev, bf.X(),
+                       c.in_channels, H * H, v->e_conv_in.cin_s);
+    if ((rc = launch_status("k_nchw_to_nhwc"))) return rc;
+    if ((rc = run_conv(v->e_conv_in, bf.X(), bf.other(1), nullptr, (int)B, H, H, 1, 0, st))) return rc;
+    bf.advance(1);
+    for (int lvl = 0; lvl < L; ++lvl) {
+        for (int b = 0; b < c.num_res_blocks; ++b) {
+            if ((rc = run_res(v, v->e_down[lvl][b], bf, (int)B, H, H, st))) return rc;
+            if (!v->e_downattn[lvl].empty())
+                if ((rc = run_attn(v, v->e_downattn[lvl][b], bf, (int)B, H, H, st))) return rc;
+        }
+        if (lvl != L - 1) {
+            if ((rc = run_conv(v->e_downsample[lvl], bf.X(), bf.other(1), nullptr, (int)B, H, H, 2, 0, st))) return rc;
+            bf.advance(1);
+            H /= 2;
+        }
+    }
+    if ((rc = run_res(v, v->e_mid1, bf, (int)B, H, H, st))) return rc;
+    if ((rc = run_attn(v, v->e_midattn, bf, (int)B, H, H, st))) return rc;
+    if ((rc = run_res(v, v->e_mid2, bf, (int)B, H, H, st))) return rc;
+    if ((rc = run_gn(v, v->e_norm_out, bf.X(), bf.other(1), (int)B, H * H, 1, st))) return rc;
+    if ((rc = run_conv(v->e_conv_out, bf.other(1), bf.other(2), nullptr, (int)B, H, H, 1, 0, st))) return rc;
+    if ((rc = run_conv(v->quant, bf.other(2), bf.other(3), nullptr, (int)B, H, H, 1, 0, st))) return rc;
+    float* zq = bf.other(3);   // [B*S*S][E] (E is a multiple of 8: no channel padding)
+    const long long P = (long long)B * S * S;
+    if (prequant_dev) WMAR_HIP_CHECK(hipMemcpyAsync(prequant_dev, zq, (size_t)P * E * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_row_sqnorm, dim3((unsigned)P), dim3(64), 0, st, zq, v->znorm, E);
+    VqArgs a{};
+    a.z = zq; a.ep = v->emb_p; a.enorm = v->enorm; a.znorm = v->znorm; a.codes = (long long*)codes_dev; a.P = P;
+    a.E = E; a.n_embed = c.n_embed;
+    const size_t lds = (size_t)64 * (E + 4) * sizeof(float);
+    WMAR_HIP_CHECK(hipFuncSetAttribute((const void*)k_vq_argmin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_vq_argmin, dim3((unsigned)((P + 63) / 64)), dim3(256), lds, st, a);
+    return launch_status("k_vq_argmin");
+}
+
+}  // extern "C"

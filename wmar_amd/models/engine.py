@@ -83,10 +83,16 @@ class GPTEngine:
     def set_timing(self, on: bool):
         self._L.wmar_gpt_set_timing(self._h, 1 if on else 0)
 
+    T_CLASSES = ["embed", "qkv", "attn", "proj", "resid", "fc1", "fc2", "head", "sample"]
+
     def get_timing(self):
-        arr = (C.c_double * 5)()
-        self._L.wmar_gpt_get_timing(self._h, arr)
-        return list(arr)
+        """{class: (total_us, calls)} of the last eager generate() with timing on, and ms/step."""
+        n = len(self.T_CLASSES)
+        us = (C.c_double * n)()
+        calls = (C.c_int64 * n)()
+        step = C.c_double()
+        self._L.wmar_gpt_get_timing(self._h, us, calls, C.byref(step))
+        return {k: (us[i], calls[i]) for i, k in enumerate(self.T_CLASSES)}, step.value
 
 
 class VQGANEngine:
