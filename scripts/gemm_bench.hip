@@ -25,7 +25,7 @@ int main() {
     const int B = 64, MT = 2, D = 1536;
     hipStream_t st; hipStreamCreate(&st);
     struct Shape { const char* name; int N, K; int S; } shapes[] = {
-        {"fc1", 4 * D, D, 1}, {"fc1k64", 4 * D, 64, 1}, {"fc1k256", 4 * D, 256, 1}, {"fc1k512", 4 * D, 512, 1}, {"fc1k768", 4 * D, 768, 1}};
+        {"qkv", 3 * D, D, 1}, {"fc1", 4 * D, D, 1}, {"fc2", D, 4 * D, 5}, {"proj", D, D, 5}, {"head", 16384, D, 1}};
     // many distinct weight buffers so that weights stream from HBM (not the 256 MB infinity cache)
     const int NBUF = 12;
     size_t wmax = (size_t)16384 * D;
@@ -34,7 +34,7 @@ int main() {
     float4 *X, *out; double* stats; float *bias, *logits, *qbuf, *kc, *vc; int* pos;
     hipMalloc(&X, (size_t)64 * 4 * D * 4); hipMemset(X, 0x3c, (size_t)64 * 4 * D * 4);
     hipMalloc(&out, (size_t)8 * 64 * 4 * D * 4);
-    hipMalloc(&stats, 16 * 64 * 2 * 8); hipMemset(stats, 0, 16 * 64 * 2 * 8);
+    hipMalloc(&stats, 64 * 64 * 2 * 8); hipMemset(stats, 0, 64 * 64 * 2 * 8);
     hipMalloc(&bias, 16384 * 4); hipMemset(bias, 0, 16384 * 4);
     hipMalloc(&logits, (size_t)64 * 16384 * 4);
     hipMalloc(&qbuf, 64 * D * 4);
@@ -42,7 +42,7 @@ int main() {
     hipMalloc(&pos, 16); hipMemset(pos, 0, 16);
     for (auto& s : shapes) {
         GemmArgs a{};
-        a.Xp = X; a.bias = bias; a.KB = s.K / 8; a.NT = s.N / 32; a.MT = MT; a.S = s.S;
+        a.Xp = X; a.bias = bias; a.c1 = bias; a.KB = s.K / 8; a.NT = s.N / 32; a.MT = MT; a.S = s.S;
         a.stats = stats; a.n_chunks = 8; a.K = s.K; a.out_packed = out; a.slab_stride = (long long)s.N / 8 * MT * 64;
         a.qbuf = qbuf; a.kcache = kc; a.vcache = vc; a.pos_dev = pos; a.D = D; a.H = 24; a.hd = 64; a.Tmax = 256;
         a.logits = logits; a.V = 16384; a.B = B;
@@ -58,10 +58,13 @@ int main() {
                 for (int b = 0; b < NBUF; ++b) { a.Wp = W[b]; float us = fn(a); if (rep) { tot += us; ++n; } }
             report(var, tot / n);
         };
-        run([&](GemmArgs x) { return time_gemm<2, 4, EPI_PACKED, false, 0, 4, true>(x, 20, st); }, "mtw2 nw4 U4");
-        run([&](GemmArgs x) { return time_gemm<2, 4, EPI_PACKED, false, 3, 4, true>(x, 20, st); }, "mtw2 nw4 U4 noMFMA");
-        run([&](GemmArgs x) { return time_gemm<1, 4, EPI_PACKED, false, 0, 4, true>(x, 20, st); }, "mtw1 nw4 U4");
-        run([&](GemmArgs x) { return time_gemm<2, 4, EPI_GELU, true, 0, 4, true>(x, 20, st); }, "mtw2 nw4 U4 LN gelu");
+        a.n_chunks = 12;
+        run([&](GemmArgs x) { return time_gemm<2, 4, EPI_PACKED, false, 0, 4, true>(x, 20, st); }, "plain");
+        run([&](GemmArgs x) { return time_gemm<2, 4, EPI_PACKED, true, 0, 4, true>(x, 20, st); }, "LN");
+        run([&](GemmArgs x) { return time_gemm<2, 4, EPI_GELU, false, 0, 4, true>(x, 20, st); }, "gelu");
+        run([&](GemmArgs x) { return time_gemm<2, 4, EPI_GELU, true, 0, 4, true>(x, 20, st); }, "LN gelu");
+        run([&](GemmArgs x) { return time_gemm<2, 4, EPI_QKV, true, 0, 4, true>(x, 20, st); }, "LN qkv-epi");
+        run([&](GemmArgs x) { return time_gemm<2, 4, EPI_LOGITS, true, 0, 4, true>(x, 20, st); }, "LN logits-epi");
     }
     return 0;
 }

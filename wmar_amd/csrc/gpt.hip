@@ -34,7 +34,7 @@ __device__ __forceinline__ float4 ld_nt(const float4* p) {
 }
 
 constexpr int MAX_SLABS = 8;
-constexpr int STAT_CHUNKS_MAX = 16;
+constexpr int STAT_CHUNKS_MAX = 64;   // n_embd <= 8192
 constexpr int GEMM_STAGE = 4;   // k-blocks (of 8) per register stage of the skinny GEMM
 
 // ------------------------------------------------------------------------ weight packing
@@ -58,7 +58,7 @@ __global__ void k_pack_linear(const float* __restrict__ W, float4* __restrict__ 
     Wp[((long long)(nt + nt_off) * KB + kb) * 64 + lane] = v;
 }
 
-// out[n] = (bias ? bias[n] : 0) + sum_k W[n][k] * beta[k]   (one wave per output row)
+// out[n] = (bias ? bias[n] : 0) + sum_k W[n][k] * v[k]   (one wave per output row; v = LN beta or gamma)
 __global__ __launch_bounds__(64) void k_fold_bias(const float* __restrict__ W, const float* __restrict__ bias,
                                                   const float* __restrict__ beta, float* __restrict__ out, int K) {
     const int n = blockIdx.x, lane = threadIdx.x;
@@ -93,14 +93,16 @@ struct ResidArgs {
     int B, K;
 };
 
-template <bool EMBED>
+// S = number of partial slabs (compile-time so that every load of a wave is issued up front:
+// the kernel is a handful of dependent L2 round trips, not bandwidth).
+template <bool EMBED, int S>
 __global__ __launch_bounds__(256) void k_resid_stats(ResidArgs a) {
+    constexpr int KPW = 4;  // k-blocks per wave (host guarantees chunk length <= 4*KPW)
     __shared__ double red[4][32][2];
     const int c = blockIdx.x / a.MT, mt = blockIdx.x % a.MT;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int kb0 = (int)((long long)c * a.KB / a.n_chunks), kb1 = (int)((long long)(c + 1) * a.KB / a.n_chunks);
     const int m = mt * 32 + (lane & 31), half = lane >> 5;
-    double s = 0.0, ss = 0.0;
     const float* erow = nullptr;
     const float* prow = nullptr;
     if (EMBED) {
@@ -109,27 +111,44 @@ __global__ __launch_bounds__(256) void k_resid_stats(ResidArgs a) {
         erow = a.tok_emb + tk * a.K;
         prow = a.pos_emb + (long long)pos * a.K;
     }
-    for (int kb = kb0 + w; kb < kb1; kb += 4) {
-        const long long idx = ((long long)kb * a.MT + mt) * 64 + lane;
-        float4 v;
+    float4 v[KPW], bb[KPW], sl[KPW][S > 0 ? S : 1];
+    int kbs[KPW];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        const int kb = kb0 + w + 4 * i;
+        kbs[i] = kb < kb1 ? kb : -1;
+        const int kk = kb < kb1 ? kb : kb0;  // in-bounds dummy for idle slots
+        const long long idx = ((long long)kk * a.MT + mt) * 64 + lane;
+        const int k = kk * 8 + 4 * half;
         if (EMBED) {
-            const int k = kb * 8 + 4 * half;
-            float4 e = *(const float4*)(erow + k);
-            float4 p = *(const float4*)(prow + k);
-            v = make_float4(e.x + p.x, e.y + p.y, e.z + p.z, e.w + p.w);
+            v[i] = *(const float4*)(erow + k);
+            bb[i] = *(const float4*)(prow + k);
         } else {
-            v = a.x[idx];
-            float4 bb = *(const float4*)(a.bias + kb * 8 + 4 * half);
-            float4 acc = a.slabs[idx];
-            for (int sidx = 1; sidx < a.S; ++sidx) {
-                float4 t = a.slabs[(long long)sidx * a.slab_stride + idx];
-                acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-            }
-            v.x += bb.x + acc.x; v.y += bb.y + acc.y; v.z += bb.z + acc.z; v.w += bb.w + acc.w;
+            v[i] = a.x[idx];
+            bb[i] = *(const float4*)(a.bias + k);
+#pragma unroll
+            for (int sidx = 0; sidx < S; ++sidx) sl[i][sidx] = a.slabs[(long long)sidx * a.slab_stride + idx];
         }
-        a.x[idx] = v;
-        s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
-        ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    double s = 0.0, ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        if (kbs[i] < 0) continue;
+        float4 r;
+        if (EMBED) {
+            r = make_float4(v[i].x + bb[i].x, v[i].y + bb[i].y, v[i].z + bb[i].z, v[i].w + bb[i].w);
+        } else {
+            float4 acc = sl[i][0];
+#pragma unroll
+            for (int sidx = 1; sidx < S; ++sidx) {
+                acc.x += sl[i][sidx].x; acc.y += sl[i][sidx].y; acc.z += sl[i][sidx].z; acc.w += sl[i][sidx].w;
+            }
+            r = make_float4(v[i].x + (bb[i].x + acc.x), v[i].y + (bb[i].y + acc.y), v[i].z + (bb[i].z + acc.z),
+                            v[i].w + (bb[i].w + acc.w));
+        }
+        a.x[((long long)kbs[i] * a.MT + mt) * 64 + lane] = r;
+        s += (double)r.x + (double)r.y + (double)r.z + (double)r.w;
+        ss += (double)r.x * r.x + (double)r.y * r.y + (double)r.z * r.z + (double)r.w * r.w;
     }
     s += __shfl_xor(s, 32);
     ss += __shfl_xor(ss, 32);
@@ -144,6 +163,47 @@ __global__ __launch_bounds__(256) void k_resid_stats(ResidArgs a) {
     }
 }
 
+template <int S>
+static void launch_resid_s(const ResidArgs& r, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((k_resid_stats<false, S>), dim3(grid), dim3(256), 0, st, r);
+}
+static int launch_resid(const ResidArgs& r, int grid, hipStream_t st) {
+    switch (r.S) {
+        case 1: launch_resid_s<1>(r, grid, st); break;
+        case 2: launch_resid_s<2>(r, grid, st); break;
+        case 3: launch_resid_s<3>(r, grid, st); break;
+        case 4: launch_resid_s<4>(r, grid, st); break;
+        case 5: launch_resid_s<5>(r, grid, st); break;
+        case 6: launch_resid_s<6>(r, grid, st); break;
+        case 7: launch_resid_s<7>(r, grid, st); break;
+        case 8: launch_resid_s<8>(r, grid, st); break;
+        default: set_error("resid: bad slab count %d", r.S); return WMAR_EINVAL;
+    }
+    return launch_status("k_resid_stats");
+}
+
+// mean / rstd of row m from the per-chunk fp64 partial sums written by k_resid_stats.
+// All loads of a group of 16 chunks are issued together (one L2 round trip, not one per chunk).
+__device__ __forceinline__ void ln_row_stats(const double* __restrict__ stats, int n_chunks, int Mpad, int m, int K,
+                                             float* mu, float* rstd) {
+    double sm = 0, sq = 0;
+    for (int c0 = 0; c0 < n_chunks; c0 += 16) {
+        double2 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = min(c0 + i, n_chunks - 1);
+            v[i] = *(const double2*)(stats + ((long long)c * Mpad + m) * 2);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (c0 + i < n_chunks) { sm += v[i].x; sq += v[i].y; }
+    }
+    const double invK = 1.0 / (double)K;
+    const double mean = sm * invK;
+    *mu = (float)mean;
+    *rstd = rsqrtf((float)(sq * invK - mean * mean) + 1e-5f);
+}
+
 // ------------------------------------------------------------------------- skinny GEMM
 enum { EPI_PACKED = 0, EPI_GELU = 1, EPI_QKV = 2, EPI_LOGITS = 3 };
 
@@ -151,6 +211,7 @@ struct GemmArgs {
     const float4* Wp;          // [NT][KB][64]
     const float4* Xp;          // [KB][MT][64]
     const float* bias;         // [N] or null
+    const float* c1;           // [N] row sums of the gamma-folded weights (LN epilogue), or null
     int KB, NT, MT, S;
     // fused LayerNorm on the B operand
     const double* stats; int n_chunks; int K;
@@ -190,23 +251,6 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     float mu[MTW], rstd[MTW];
-    if (LN) {
-        const int Mpad = a.MT * 32;
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) {
-            const int m = (mt0 + i) * 32 + (lane & 31);
-            double sm = 0, sq = 0;
-            for (int c = 0; c < a.n_chunks; ++c) {
-                const double* p = a.stats + ((long long)c * Mpad + m) * 2;
-                sm += p[0]; sq += p[1];
-            }
-            double mean = sm / a.K;
-            double var = sq / a.K - mean * mean;
-            mu[i] = (float)mean;
-            rstd[i] = (float)(1.0 / sqrt(var + 1e-5));
-        }
-    }
-
     const float4* Wp = a.Wp + (long long)nt * a.KB * 64 + lane;
     const float4* Xp = a.Xp + (long long)mt0 * 64 + lane;
     const long long xstep = (long long)a.MT * 64;
@@ -221,31 +265,36 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
         _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
             XBUF[u][i] = (ABL == 1) ? make_float4(1.f, 2.f, 3.f, (float)kk) : Xp[(long long)kk * xstep + i * 64]; \
     }
+#define WMAR_LN_PROLOGUE                                                                        \
+    if (LN) {                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
+            ln_row_stats(a.stats, a.n_chunks, a.MT * 32, (mt0 + i) * 32 + (lane & 31), a.K, &mu[i], &rstd[i]); \
+    }
+#define WMAR_LNX(XV)
 #define WMAR_MMA1(WV, XV)                                                                       \
     {                                                                                           \
-        float4 xv[MTW];                                                                         \
-        _Pragma("unroll") for (int i = 0; i < MTW; ++i) {                                      \
-            xv[i] = XV[i];                                                                      \
-            if (LN) {                                                                           \
-                xv[i].x = (xv[i].x - mu[i]) * rstd[i]; xv[i].y = (xv[i].y - mu[i]) * rstd[i];   \
-                xv[i].z = (xv[i].z - mu[i]) * rstd[i]; xv[i].w = (xv[i].w - mu[i]) * rstd[i];   \
-            }                                                                                   \
-        }                                                                                       \
         if (ABL == 3) {                                                                         \
             _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                    \
-                acc[i][0] += WV.x * xv[i].x + WV.y * xv[i].y + WV.z * xv[i].z + WV.w * xv[i].w; \
+                acc[i][0] += WV.x * XV[i].x + WV.y * XV[i].y + WV.z * XV[i].z + WV.w * XV[i].w; \
         } else {                                                                                \
         _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV.x, xv[i].x, acc[i], 0, 0, 0);      \
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV.x, XV[i].x, acc[i], 0, 0, 0);      \
         _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV.y, xv[i].y, acc[i], 0, 0, 0);      \
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV.y, XV[i].y, acc[i], 0, 0, 0);      \
         _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV.z, xv[i].z, acc[i], 0, 0, 0);      \
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV.z, XV[i].z, acc[i], 0, 0, 0);      \
         _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV.w, xv[i].w, acc[i], 0, 0, 0);      \
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV.w, XV[i].w, acc[i], 0, 0, 0);      \
         }                                                                                       \
     }
-#define WMAR_MMA(WBUF, XBUF) _Pragma("unroll") for (int u = 0; u < U; ++u) WMAR_MMA1(WBUF[u], XBUF[u])
+// the normalisation of k-block u+1 is issued ahead of the MFMAs of k-block u (VALU under MFMA),
+// and each k-block only waits for its own loads
+#define WMAR_MMA(WBUF, XBUF)                                                                    \
+    WMAR_LNX(XBUF[0])                                                                           \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                            \
+        if (u + 1 < U) { WMAR_LNX(XBUF[u + 1]) }                                                \
+        WMAR_MMA1(WBUF[u], XBUF[u])                                                             \
+    }
     int kb = kb0;
     const int nfull = (kb1 - kb0) / (2 * U);
     if (nfull > 0) {
@@ -260,6 +309,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
         // registers), which serialises load -> wait -> 4 MFMAs.
         WMAR_LOAD(wA, xA, WMAR_STAGE_KB(0))
         __builtin_amdgcn_sched_barrier(0);
+        // LayerNorm statistics are fetched AFTER the first operand loads are in flight
+        WMAR_LN_PROLOGUE
+        __builtin_amdgcn_sched_barrier(0);
         for (int it = 0; it < nfull; ++it) {
             WMAR_LOAD(wB, xB, WMAR_STAGE_KB(2 * it + 1))
             __builtin_amdgcn_sched_barrier(0);
@@ -273,15 +325,20 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
         }
 #undef WMAR_STAGE_KB
         kb = kb0 + nst * U;
+    } else {
+        WMAR_LN_PROLOGUE
     }
     for (; kb < kb1; ++kb) {  // tail (slices that are not a multiple of 2U blocks)
         float4 wv = ld_nt(Wp + (long long)kb * 64);
         float4 xt[MTW];
 #pragma unroll
         for (int i = 0; i < MTW; ++i) xt[i] = Xp[(long long)kb * xstep + i * 64];
+        WMAR_LNX(xt)
         WMAR_MMA1(wv, xt)
     }
 #undef WMAR_MMA1
+#undef WMAR_LNX
+#undef WMAR_LN_PROLOGUE
 #undef WMAR_LOAD
 #undef WMAR_MMA
 
@@ -305,6 +362,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
         const int mt = mt0 + i;
         const int n = nt * 32 + g * 8 + half * 4;       // first of 4 consecutive output columns
         const int m = mt * 32 + (lane & 31);
+        if (LN) {
+            // LN(x) W^T = rstd * (x W'^T - mean * rowsum(W')) + (bias + W beta):  the main loop ran on raw x
+            const float4 cc = *(const float4*)(a.c1 + n);
+            const float mm = mu[i], rs = rstd[i];
+            o[0] = rs * (o[0] - mm * cc.x); o[1] = rs * (o[1] - mm * cc.y);
+            o[2] = rs * (o[2] - mm * cc.z); o[3] = rs * (o[3] - mm * cc.w);
+        }
         if (a.bias) {
             float4 bb = *(const float4*)(a.bias + n);
             o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w;
@@ -339,10 +403,18 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
 // One wave per (sequence, head).  K/V rows are hd floats; LPR = hd/4 lanes cover a row with
 // float4s and RPI = 64/LPR rows are read per wave-wide load (1 KiB, coalesced).
 struct AttnArgs {
-    const float* qbuf;   // [M][D]
-    const float* kcache; // [B][H][Tmax][hd] (this layer)
-    const float* vcache;
-    float4* y;           // packed [KB][MT][64]
+    // The QKV projection arrives as S split-K partial slabs in packed layout (columns
+    // [q | k | v], 3*D wide).  The attention wave of (sequence, head) finishes its own
+    // 3 x hd columns -- LayerNorm algebra, bias -- appends k and v to the cache and goes on.
+    const float4* qkv_slabs;   // [S][(3D/8)][MT][64]
+    long long slab_stride;     // float4 units
+    int S;
+    const double* stats; int n_chunks; int K;   // LN1 row statistics (see k_resid_stats)
+    const float* c1;           // [3D] row sums of the gamma-folded QKV weights
+    const float* bias;         // [3D] bias + W beta
+    float* kcache;             // [B][H][Tmax][hd] (this layer)
+    float* vcache;
+    float4* y;                 // packed [KB][MT][64]
     const int* pos_dev;
     int D, H, Tmax, MT;
     float scale;
@@ -351,42 +423,97 @@ struct AttnArgs {
 template <int HD>
 __global__ __launch_bounds__(64) void k_attn_decode(AttnArgs a) {
     constexpr int LPR = HD / 4, RPI = 64 / LPR;
-    extern __shared__ float sc[];  // [Tmax] scores / probabilities
+    constexpr int CH = 16;                 // 1-KiB loads per chunk: CH*RPI cache rows, 16 KiB in flight per wave
+    constexpr int ROWS = CH * RPI;
+    extern __shared__ float sc[];          // [round_up(Tmax, ROWS)] scores, then probabilities
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int lane = threadIdx.x;
     const int T = *a.pos_dev + 1;
     const int sub = lane % LPR, rsel = lane / LPR;
-    const float4 q = *(const float4*)(a.qbuf + (long long)b * a.D + h * HD + sub * 4);
-    const float* K = a.kcache + ((long long)b * a.H + h) * a.Tmax * HD;
-    const float* Vv = a.vcache + ((long long)b * a.H + h) * a.Tmax * HD;
+    float* Kc = a.kcache + ((long long)b * a.H + h) * a.Tmax * HD + sub * 4;
+    float* Vc = a.vcache + ((long long)b * a.H + h) * a.Tmax * HD + sub * 4;
+    const float* K = Kc;
+    const float* Vv = Vc;
+    const int nchunk = (T + ROWS - 1) / ROWS;
 
+    // rows past T are clamped to T-1 (always resident) and masked out of the softmax
+#define WMAR_ATT_LOAD(BUF, BASE, C0)                                                     \
+    _Pragma("unroll") for (int u = 0; u < CH; ++u) {                                     \
+        const int t = min((C0) * ROWS + u * RPI + rsel, T - 1);                          \
+        BUF[u] = *(const float4*)((BASE) + (long long)t * HD);                           \
+    }
+    // row T-1 is the token of this step: take it from registers, not from the just-written cache
+#define WMAR_ATT_FIX(BUF, NEW, C0)                                                       \
+    if (((C0) + 1) * ROWS >= T) {                                                        \
+        _Pragma("unroll") for (int u = 0; u < CH; ++u)                                   \
+            if ((C0) * ROWS + u * RPI + rsel >= T - 1) BUF[u] = NEW;                     \
+    }
+    float4 bufA[CH], bufB[CH];
+    float4 q, knew, vnew;
     float mx = -INFINITY;
-    for (int t0 = 0; t0 < T; t0 += RPI * 4) {
-        float4 kv[4];
+#define WMAR_ATT_SCORE(BUF, C0)                                                          \
+    _Pragma("unroll") for (int u = 0; u < CH; ++u) {                                     \
+        float p = BUF[u].x * q.x + BUF[u].y * q.y + BUF[u].z * q.z + BUF[u].w * q.w;     \
+        _Pragma("unroll") for (int o = 1; o < LPR; o <<= 1) p += __shfl_xor(p, o);       \
+        p *= a.scale;                                                                    \
+        const int t = (C0) * ROWS + u * RPI + rsel;                                      \
+        if (t >= T) p = -INFINITY;                                                       \
+        if (sub == 0) sc[t] = p;                                                         \
+        mx = fmaxf(mx, p);                                                               \
+    }
+    WMAR_ATT_LOAD(bufA, K, 0)     // the first 16 KiB of K are in flight while q/k/v are finished
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- finish this head's q, k, v for the new token from the split-K slabs
+    {
+        float mu, rstd;
+        ln_row_stats(a.stats, a.n_chunks, a.MT * 32, b, a.K, &mu, &rstd);
+        const int mt = b >> 5;
+        float4 r[3];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            int t = t0 + u * RPI + rsel;
-            kv[u] = (t < T) ? *(const float4*)(K + (long long)t * HD + sub * 4) : make_float4(0, 0, 0, 0);
+        for (int which = 0; which < 3; ++which) {
+            const int n = which * a.D + h * HD + sub * 4;          // first of this lane's 4 columns
+            const long long idx = ((long long)(n >> 3) * a.MT + mt) * 64 + (b & 31) + 32 * ((n >> 2) & 1);
+            float4 sl[MAX_SLABS];
+#pragma unroll
+            for (int sidx = 0; sidx < MAX_SLABS; ++sidx)
+                sl[sidx] = a.qkv_slabs[(long long)min(sidx, a.S - 1) * a.slab_stride + idx];
+            float4 acc = sl[0];
+#pragma unroll
+            for (int sidx = 1; sidx < MAX_SLABS; ++sidx)
+                if (sidx < a.S) { acc.x += sl[sidx].x; acc.y += sl[sidx].y; acc.z += sl[sidx].z; acc.w += sl[sidx].w; }
+            const float4 cc = *(const float4*)(a.c1 + n);
+            const float4 bb = *(const float4*)(a.bias + n);
+            r[which] = make_float4(rstd * (acc.x - mu * cc.x) + bb.x, rstd * (acc.y - mu * cc.y) + bb.y,
+                                   rstd * (acc.z - mu * cc.z) + bb.z, rstd * (acc.w - mu * cc.w) + bb.w);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float p = kv[u].x * q.x + kv[u].y * q.y + kv[u].z * q.z + kv[u].w * q.w;
-#pragma unroll
-            for (int o = 1; o < LPR; o <<= 1) p += __shfl_xor(p, o);
-            p *= a.scale;
-            int t = t0 + u * RPI + rsel;
-            if (t < T) {
-                if (sub == 0) sc[t] = p;
-                mx = fmaxf(mx, p);
-            }
+        q = r[0]; knew = r[1]; vnew = r[2];
+        if (rsel == 0) {   // present = (k, v) of this step -> cache row T-1 (mingpt.py:77)
+            *(float4*)(Kc + (long long)(T - 1) * HD) = knew;
+            *(float4*)(Vc + (long long)(T - 1) * HD) = vnew;
         }
     }
+
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c = 0; c < nchunk; c += 2) {
+        if (c + 1 < nchunk) { WMAR_ATT_LOAD(bufB, K, c + 1) }
+        __builtin_amdgcn_sched_barrier(0);
+        WMAR_ATT_FIX(bufA, knew, c)
+        WMAR_ATT_SCORE(bufA, c)
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < nchunk) { WMAR_ATT_LOAD(bufA, K, c + 2) }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < nchunk) { WMAR_ATT_FIX(bufB, knew, c + 1) WMAR_ATT_SCORE(bufB, c + 1) }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // the first V chunk travels while the softmax is normalised
+    WMAR_ATT_LOAD(bufA, Vv, 0)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     __syncthreads();
     float sum = 0.f;
-    for (int t = lane; t < T; t += 64) {
-        float e = __expf(sc[t] - mx);
+    for (int t = lane; t < nchunk * ROWS; t += 64) {
+        float e = __expf(sc[t] - mx);   // -inf -> 0 for the masked tail
         sc[t] = e;
         sum += e;
     }
@@ -396,21 +523,26 @@ __global__ __launch_bounds__(64) void k_attn_decode(AttnArgs a) {
     const float inv = 1.0f / sum;
 
     float4 acc = make_float4(0, 0, 0, 0);
-    for (int t0 = 0; t0 < T; t0 += RPI * 4) {
-        float4 vv[4];
-        float pp[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            int t = t0 + u * RPI + rsel;
-            bool ok = t < T;
-            vv[u] = ok ? *(const float4*)(Vv + (long long)t * HD + sub * 4) : make_float4(0, 0, 0, 0);
-            pp[u] = ok ? sc[t] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc.x += pp[u] * vv[u].x; acc.y += pp[u] * vv[u].y; acc.z += pp[u] * vv[u].z; acc.w += pp[u] * vv[u].w;
-        }
+#define WMAR_ATT_PV(BUF, C0)                                                             \
+    _Pragma("unroll") for (int u = 0; u < CH; ++u) {                                     \
+        const float pp = sc[(C0) * ROWS + u * RPI + rsel];                               \
+        acc.x += pp * BUF[u].x; acc.y += pp * BUF[u].y; acc.z += pp * BUF[u].z; acc.w += pp * BUF[u].w; \
     }
+    for (int c = 0; c < nchunk; c += 2) {
+        if (c + 1 < nchunk) { WMAR_ATT_LOAD(bufB, Vv, c + 1) }
+        __builtin_amdgcn_sched_barrier(0);
+        WMAR_ATT_FIX(bufA, vnew, c)
+        WMAR_ATT_PV(bufA, c)
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < nchunk) { WMAR_ATT_LOAD(bufA, Vv, c + 2) }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < nchunk) { WMAR_ATT_FIX(bufB, vnew, c + 1) WMAR_ATT_PV(bufB, c + 1) }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef WMAR_ATT_LOAD
+#undef WMAR_ATT_FIX
+#undef WMAR_ATT_SCORE
+#undef WMAR_ATT_PV
 #pragma unroll
     for (int o = LPR; o < 64; o <<= 1) {
         acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o);
@@ -433,7 +565,7 @@ using namespace wmar;
 // ------------------------------------------------------------------------------ engine
 struct LayerW {
     float4 *wqkv, *wproj, *wfc1, *wfc2;
-    float *bqkv, *bproj, *bfc1, *bfc2;
+    float *bqkv, *bproj, *bfc1, *bfc2, *cqkv, *cfc1;
 };
 
 struct wmar_gpt {
@@ -442,10 +574,10 @@ struct wmar_gpt {
     std::vector<void*> allocs;
     int64_t bytes = 0;
     std::vector<LayerW> layers;
-    float *tok_emb = nullptr, *pos_emb = nullptr, *bhead = nullptr;
+    float *tok_emb = nullptr, *pos_emb = nullptr, *bhead = nullptr, *chead = nullptr;
     float4* whead = nullptr;
     // workspaces
-    float4 *x = nullptr, *y = nullptr, *hbuf = nullptr, *slabs = nullptr;
+    float4 *x = nullptr, *y = nullptr, *hbuf = nullptr, *slabs = nullptr, *qkv_slabs = nullptr;
     float* qbuf = nullptr;
     double* stats = nullptr;
     float *kcache = nullptr, *vcache = nullptr;
@@ -455,6 +587,7 @@ struct wmar_gpt {
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int timing = 0;
+    int force_s[3] = {0, 0, 0};   // tuning knobs: WMAR_S_QKV / WMAR_S_PROJ / WMAR_S_FC2
     double step_ms = 0.0;
     // per-launch event timing (eager mode only)
     struct Span { int cls; hipEvent_t a, b; };
@@ -583,10 +716,10 @@ int gemm_dispatch(GemmArgs a, bool allow_split, hipStream_t st) {
 }
 
 // split-K GEMM writing partial slabs; reports the S it used
-int gemm_split(GemmArgs a, int* S_out, hipStream_t st) {
+int gemm_split(GemmArgs a, int* S_out, hipStream_t st, int force_S = 0) {
     constexpr int NW = 4;
     if (a.MT % 2 == 0) {
-        a.S = pick_split(a.NT * (a.MT / 2), a.KB, NW);
+        a.S = force_S > 0 ? force_S : pick_split(a.NT * (a.MT / 2), a.KB, NW);
         *S_out = a.S;
         return launch_gemm<2, NW, EPI_PACKED, false>(a, st);
     }
@@ -595,12 +728,8 @@ int gemm_split(GemmArgs a, int* S_out, hipStream_t st) {
     return launch_gemm<1, NW, EPI_PACKED, false>(a, st);
 }
 
-int stat_chunks(int KB) {
-    int c = KB / 24;
-    if (c < 1) c = 1;
-    if (c > STAT_CHUNKS_MAX) c = STAT_CHUNKS_MAX;
-    return c;
-}
+// chunks of <= 16 k-blocks: one k_resid_stats workgroup (4 waves x 4 blocks) per chunk and row tile
+int stat_chunks(int KB) { return (KB + 15) / 16; }
 
 struct StepIO {
     const long long* tok;  // row m's token: tok[m*stride + (use_pos ? pos : 0)]
@@ -621,7 +750,7 @@ int enqueue_step(wmar_gpt* g, int64_t B, const StepIO& io, hipStream_t st) {
     r.tok_emb = g->tok_emb; r.pos_emb = g->pos_emb; r.tok = io.tok; r.tok_stride = io.tok_stride;
     r.tok_use_pos = io.tok_use_pos; r.pos_dev = g->pos_dev; r.B = (int)B; r.K = D;
     g->span_begin(WMAR_T_EMBED, st);
-    hipLaunchKernelGGL(k_resid_stats<true>, dim3(nch * MT), dim3(256), 0, st, r);
+    hipLaunchKernelGGL((k_resid_stats<true, 0>), dim3(nch * MT), dim3(256), 0, st, r);
     g->span_end(st);
     if ((rc = launch_status("k_resid_stats<embed>"))) return rc;
 
@@ -631,29 +760,35 @@ int enqueue_step(wmar_gpt* g, int64_t B, const StepIO& io, hipStream_t st) {
         if (l > 0) {  // fold the previous layer's FC2 partial sums into the residual stream
             r.slabs = g->slabs; r.slab_stride = act; r.S = S_prev; r.bias = bias_prev;
             g->span_begin(WMAR_T_RESID, st);
-            hipLaunchKernelGGL(k_resid_stats<false>, dim3(nch * MT), dim3(256), 0, st, r);
+            rc = launch_resid(r, nch * MT, st);
             g->span_end(st);
-            if ((rc = launch_status("k_resid_stats"))) return rc;
+            if (rc) return rc;
         }
         if (l == g->L) break;
         const LayerW& w = g->layers[l];
         GemmArgs a{};
         a.MT = MT; a.B = (int)B; a.stats = g->stats; a.n_chunks = nch; a.K = D;
         a.pos_dev = g->pos_dev; a.D = D; a.H = g->H; a.hd = g->hd; a.Tmax = g->Tmax;
-        // LN1 -> QKV (+bias) -> q buffer and KV cache
-        a.Wp = w.wqkv; a.Xp = g->x; a.bias = w.bqkv; a.KB = KBD; a.NT = 3 * D / 32;
-        a.qbuf = g->qbuf;
+        // QKV projection of the RAW residual stream as split-K slabs; LN1, bias and the KV-cache
+        // append are finished per (sequence, head) in the attention kernel's prologue
+        a.Wp = w.wqkv; a.Xp = g->x; a.bias = nullptr; a.c1 = nullptr; a.KB = KBD; a.NT = 3 * D / 32;
+        const long long act3 = 3 * act;
+        a.out_packed = g->qkv_slabs; a.slab_stride = act3;
         const long long lstride = (long long)g->Bmax * g->H * g->Tmax * g->hd;
-        a.kcache = g->kcache + l * lstride; a.vcache = g->vcache + l * lstride;
+        int S_qkv = 1;
         g->span_begin(WMAR_T_QKV, st);
-        rc = gemm_dispatch<EPI_QKV, true>(a, false, st);
+        // measured: one slab (no K split across workgroups) beats every split for this shape --
+        // more, thinner workgroups per CU contend for the same L1 fill path
+        rc = gemm_split(a, &S_qkv, st, g->force_s[0] > 0 ? g->force_s[0] : 1);
         g->span_end(st);
         if (rc) return rc;
         // attention
         AttnArgs t{};
-        t.qbuf = g->qbuf; t.kcache = a.kcache; t.vcache = a.vcache; t.y = g->y; t.pos_dev = g->pos_dev;
+        t.qkv_slabs = g->qkv_slabs; t.slab_stride = act3; t.S = S_qkv; t.stats = g->stats; t.n_chunks = nch; t.K = D;
+        t.c1 = w.cqkv; t.bias = w.bqkv;
+        t.kcache = g->kcache + l * lstride; t.vcache = g->vcache + l * lstride; t.y = g->y; t.pos_dev = g->pos_dev;
         t.D = D; t.H = g->H; t.Tmax = g->Tmax; t.MT = MT; t.scale = 1.0f / sqrtf((float)g->hd);
-        const size_t lds = (size_t)g->Tmax * sizeof(float);
+        const size_t lds = (size_t)((g->Tmax + 127) / 128 * 128) * sizeof(float);
         const dim3 grid((unsigned)(B * g->H));
         g->span_begin(WMAR_T_ATTN, st);
         if (g->hd == 64) hipLaunchKernelGGL(k_attn_decode<64>, grid, dim3(64), lds, st, t);
@@ -663,21 +798,21 @@ int enqueue_step(wmar_gpt* g, int64_t B, const StepIO& io, hipStream_t st) {
         if ((rc = launch_status("k_attn_decode"))) return rc;
         // proj (split-K partial slabs; bias + residual folded by the next k_resid_stats)
         GemmArgs p = a;
-        p.Wp = w.wproj; p.Xp = g->y; p.bias = nullptr; p.KB = KBD; p.NT = D / 32;
+        p.Wp = w.wproj; p.Xp = g->y; p.bias = nullptr; p.c1 = nullptr; p.KB = KBD; p.NT = D / 32;
         p.out_packed = g->slabs; p.slab_stride = act;
         int S_proj = 1;
         g->span_begin(WMAR_T_PROJ, st);
-        rc = gemm_split(p, &S_proj, st);
+        rc = gemm_split(p, &S_proj, st, g->force_s[1]);
         g->span_end(st);
         if (rc) return rc;
         r.slabs = g->slabs; r.slab_stride = act; r.S = S_proj; r.bias = w.bproj;
         g->span_begin(WMAR_T_RESID, st);
-        hipLaunchKernelGGL(k_resid_stats<false>, dim3(nch * MT), dim3(256), 0, st, r);
+        rc = launch_resid(r, nch * MT, st);
         g->span_end(st);
-        if ((rc = launch_status("k_resid_stats"))) return rc;
+        if (rc) return rc;
         // LN2 -> FC1 (+bias, GELU) -> packed hidden
         GemmArgs f = a;
-        f.Wp = w.wfc1; f.Xp = g->x; f.bias = w.bfc1; f.KB = KBD; f.NT = 4 * D / 32;
+        f.Wp = w.wfc1; f.Xp = g->x; f.bias = w.bfc1; f.c1 = w.cfc1; f.KB = KBD; f.NT = 4 * D / 32;
         f.out_packed = g->hbuf; f.slab_stride = 0;
         g->span_begin(WMAR_T_FC1, st);
         rc = gemm_dispatch<EPI_GELU, true>(f, false, st);
@@ -685,10 +820,10 @@ int enqueue_step(wmar_gpt* g, int64_t B, const StepIO& io, hipStream_t st) {
         if (rc) return rc;
         // FC2 (split-K partial slabs)
         GemmArgs q = a;
-        q.Wp = w.wfc2; q.Xp = g->hbuf; q.bias = nullptr; q.KB = KBF; q.NT = D / 32;
+        q.Wp = w.wfc2; q.Xp = g->hbuf; q.bias = nullptr; q.c1 = nullptr; q.KB = KBF; q.NT = D / 32;
         q.out_packed = g->slabs; q.slab_stride = act;
         g->span_begin(WMAR_T_FC2, st);
-        rc = gemm_split(q, &S_prev, st);
+        rc = gemm_split(q, &S_prev, st, g->force_s[2] > 0 ? g->force_s[2] : (MT % 2 == 0 && KBF >= 128 ? 4 : 0));
         g->span_end(st);
         if (rc) return rc;
         bias_prev = w.bfc2;
@@ -697,7 +832,7 @@ int enqueue_step(wmar_gpt* g, int64_t B, const StepIO& io, hipStream_t st) {
     GemmArgs hsd{};
     hsd.MT = MT; hsd.B = (int)B; hsd.stats = g->stats; hsd.n_chunks = nch; hsd.K = D;
     hsd.Wp = g->whead; hsd.Xp = g->x; hsd.KB = KBD; hsd.NT = g->V / 32;
-    hsd.bias = g->bhead; hsd.logits = io.logits; hsd.V = g->V;
+    hsd.bias = g->bhead; hsd.c1 = g->chead; hsd.logits = io.logits; hsd.V = g->V;
     g->span_begin(WMAR_T_HEAD, st);
     rc = gemm_dispatch<EPI_LOGITS, true>(hsd, false, st);
     g->span_end(st);
@@ -713,7 +848,7 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
     WMAR_REQUIRE(cfg && names && tensors_dev && out, "gpt_create: null argument");
     WMAR_REQUIRE(cfg->n_embd % cfg->n_head == 0, "n_embd %% n_head != 0");
     const int D = cfg->n_embd, H = cfg->n_head, hd = D / H, V = cfg->vocab_size, L = cfg->n_layer;
-    WMAR_REQUIRE(D % 32 == 0 && V % 32 == 0, "n_embd and vocab_size must be multiples of 32 (got %d, %d)", D, V);
+    WMAR_REQUIRE(D % 32 == 0 && V % 32 == 0 && D <= 8192, "n_embd (<= 8192) and vocab_size must be multiples of 32 (got %d, %d)", D, V);
     WMAR_REQUIRE(hd == 32 || hd == 64 || hd == 128, "head_dim %d unsupported (32, 64, 128)", hd);
     WMAR_REQUIRE(cfg->max_batch >= 1 && cfg->max_batch <= 128, "max_batch must be in 1..128");
     WMAR_REQUIRE(cfg->block_size >= 1 && L >= 1, "bad block_size / n_layer");
@@ -723,6 +858,13 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
     auto* g = new wmar_gpt();
     g->cfg = *cfg; g->D = D; g->H = H; g->hd = hd; g->V = V; g->L = L; g->Tmax = cfg->block_size; g->Bmax = cfg->max_batch;
     g->MTmax = mt_for(cfg->max_batch);
+    {
+        const char* names_s[3] = {"WMAR_S_QKV", "WMAR_S_PROJ", "WMAR_S_FC2"};
+        for (int i = 0; i < 3; ++i) {
+            const char* e = getenv(names_s[i]);
+            if (e) g->force_s[i] = atoi(e) > MAX_SLABS ? MAX_SLABS : atoi(e);
+        }
+    }
     int rc = WMAR_OK;
     auto need = [&](const std::string& k) -> const float* {
         const float* p = tm.get(k);
@@ -741,6 +883,8 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
         TRY(pack(g, hw, g->whead, V, D, 0, st, lfw));
         TRY(g->alloc(&g->bhead, (size_t)V));
         TRY(fold_bias(hw, nullptr, lfb, g->bhead, V, D, st));
+        TRY(g->alloc(&g->chead, (size_t)V));
+        TRY(fold_bias(hw, nullptr, lfw, g->chead, V, D, st));
     }
     g->layers.resize(L);
     for (int l = 0; l < L && rc == WMAR_OK; ++l) {
@@ -761,6 +905,10 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
         TRY(fold_bias(qw, qb, l1b, w.bqkv, D, D, st));
         TRY(fold_bias(kw, kb, l1b, w.bqkv + D, D, D, st));
         TRY(fold_bias(vw, vb, l1b, w.bqkv + 2 * D, D, D, st));
+        TRY(g->alloc(&w.cqkv, (size_t)3 * D));
+        TRY(fold_bias(qw, nullptr, l1w, w.cqkv, D, D, st));
+        TRY(fold_bias(kw, nullptr, l1w, w.cqkv + D, D, D, st));
+        TRY(fold_bias(vw, nullptr, l1w, w.cqkv + 2 * D, D, D, st));
         TRY(g->alloc(&w.wproj, (size_t)D * D / 4));
         TRY(pack(g, pw, w.wproj, D, D, 0, st));
         TRY(copy_vec(g, &w.bproj, pb, D, st));
@@ -768,6 +916,8 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
         TRY(pack(g, f1w, w.wfc1, 4 * D, D, 0, st, l2w));
         TRY(g->alloc(&w.bfc1, (size_t)4 * D));
         TRY(fold_bias(f1w, f1b, l2b, w.bfc1, 4 * D, D, st));
+        TRY(g->alloc(&w.cfc1, (size_t)4 * D));
+        TRY(fold_bias(f1w, nullptr, l2w, w.cfc1, 4 * D, D, st));
         TRY(g->alloc(&w.wfc2, (size_t)4 * D * D / 4));
         TRY(pack(g, f2w, w.wfc2, D, 4 * D, 0, st));
         TRY(copy_vec(g, &w.bfc2, f2b, D, st));
@@ -777,6 +927,7 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
     TRY(g->alloc(&g->y, Mpad * D / 4));
     TRY(g->alloc(&g->hbuf, Mpad * 4 * D / 4));
     TRY(g->alloc(&g->slabs, (size_t)MAX_SLABS * Mpad * D / 4));
+    TRY(g->alloc(&g->qkv_slabs, (size_t)MAX_SLABS * Mpad * 3 * D / 4));
     TRY(g->alloc(&g->qbuf, Mpad * D));
     TRY(g->alloc(&g->stats, (size_t)STAT_CHUNKS_MAX * Mpad * 2));
     const size_t kv = (size_t)L * g->Bmax * H * g->Tmax * hd;
