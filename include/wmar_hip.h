@@ -162,6 +162,11 @@ int wmar_gpt_generate(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_para
 #define WMAR_T_SAMPLE 8  /* fused watermark + sampling                         */
 #define WMAR_T_NCLASS 9
 int wmar_gpt_set_timing(wmar_gpt* g, int32_t enabled);
+/* Replays ONE role's kernel `iters` times back to back on `stream` (cycling through the layers, so
+ * weights stream from HBM as in a real step) between two HIP events: *avg_us = average per launch,
+ * launch boundary included.  kv_len = cached rows the attention role reads. */
+int wmar_gpt_profile_role(wmar_gpt* g, int32_t role, int64_t B, int32_t kv_len, int32_t iters, void* stream,
+                          double* avg_us);
 /* total_us[c], calls[c] for each class; *step_ms = average wall time of one decode step (any mode). */
 int wmar_gpt_get_timing(wmar_gpt* g, double* total_us, int64_t* calls, double* step_ms);
 

@@ -17,7 +17,7 @@ SYMBOLS = [
     "wmar_last_error", "wmar_version", "wmar_key_row_words", "wmar_key_table_rows", "wmar_key_table_build",
     "wmar_key_greenlist", "wmar_wm_process_logits", "wmar_sample_fused", "wmar_detect", "wmar_detect_num_ngrams",
     "wmar_gpt_create", "wmar_gpt_destroy", "wmar_gpt_device_bytes", "wmar_gpt_decode_step", "wmar_gpt_generate",
-    "wmar_gpt_set_timing", "wmar_gpt_get_timing", "wmar_vq_create", "wmar_vq_destroy", "wmar_vq_device_bytes",
+    "wmar_gpt_set_timing", "wmar_gpt_get_timing", "wmar_gpt_profile_role", "wmar_vq_create", "wmar_vq_destroy", "wmar_vq_device_bytes",
     "wmar_vq_decode", "wmar_vq_encode",
 ]
 
@@ -97,6 +97,7 @@ def load():
     L.wmar_gpt_decode_step.argtypes = [vp, vp, i64, i32, vp, vp]
     L.wmar_gpt_generate.argtypes = [vp, C.POINTER(WmCtx), C.POINTER(SampleParams), vp, i64, i32, vp, vp, vp, vp]
     L.wmar_gpt_set_timing.argtypes = [vp, i32]
+    L.wmar_gpt_profile_role.argtypes = [vp, i32, i64, i32, i32, vp, C.POINTER(f64)]
     L.wmar_gpt_get_timing.argtypes = [vp, C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]
     if hasattr(L, "wmar_vq_create"):
         L.wmar_vq_create.argtypes = [C.POINTER(VqConfig), C.POINTER(C.c_char_p), C.POINTER(vp), i32, vp, C.POINTER(vp)]

@@ -723,7 +723,7 @@ int gemm_split(GemmArgs a, int* S_out, hipStream_t st, int force_S = 0) {
         *S_out = a.S;
         return launch_gemm<2, NW, EPI_PACKED, false>(a, st);
     }
-    a.S = pick_split(a.NT * a.MT, a.KB, NW);
+    a.S = force_S > 0 ? force_S : pick_split(a.NT * a.MT, a.KB, NW);
     *S_out = a.S;
     return launch_gemm<1, NW, EPI_PACKED, false>(a, st);
 }
@@ -738,53 +738,71 @@ struct StepIO {
     float* logits;
 };
 
-int enqueue_step(wmar_gpt* g, int64_t B, const StepIO& io, hipStream_t st) {
-    const int MT = mt_for(B);
-    const int D = g->D, KBD = D / 8, KBF = 4 * D / 8;
-    const int nch = stat_chunks(KBD);
-    const long long act = (long long)KBD * MT * 64;  // float4 units of one [M][D] packed activation
-    int rc;
-
+// One decode step = the launches below, in order.  Each role is its own function so that
+// bench.py can also replay a single role back to back (wmar_gpt_profile_role).
+struct StepPlan {
+    wmar_gpt* g;
+    int64_t B;
+    StepIO io;
+    hipStream_t st;
+    int MT, D, KBD, KBF, nch;
+    long long act;
     ResidArgs r{};
-    r.x = g->x; r.stats = g->stats; r.KB = KBD; r.MT = MT; r.n_chunks = nch;
-    r.tok_emb = g->tok_emb; r.pos_emb = g->pos_emb; r.tok = io.tok; r.tok_stride = io.tok_stride;
-    r.tok_use_pos = io.tok_use_pos; r.pos_dev = g->pos_dev; r.B = (int)B; r.K = D;
-    g->span_begin(WMAR_T_EMBED, st);
-    hipLaunchKernelGGL((k_resid_stats<true, 0>), dim3(nch * MT), dim3(256), 0, st, r);
-    g->span_end(st);
-    if ((rc = launch_status("k_resid_stats<embed>"))) return rc;
+    int S_qkv = 1, S_proj = 1, S_fc2 = 1;
 
-    int S_prev = 0;
-    const float* bias_prev = nullptr;
-    for (int l = 0; l <= g->L; ++l) {
-        if (l > 0) {  // fold the previous layer's FC2 partial sums into the residual stream
-            r.slabs = g->slabs; r.slab_stride = act; r.S = S_prev; r.bias = bias_prev;
-            g->span_begin(WMAR_T_RESID, st);
-            rc = launch_resid(r, nch * MT, st);
-            g->span_end(st);
-            if (rc) return rc;
-        }
-        if (l == g->L) break;
-        const LayerW& w = g->layers[l];
+    StepPlan(wmar_gpt* g_, int64_t B_, const StepIO& io_, hipStream_t st_) : g(g_), B(B_), io(io_), st(st_) {
+        MT = mt_for(B); D = g->D; KBD = D / 8; KBF = 4 * D / 8; nch = stat_chunks(KBD);
+        act = (long long)KBD * MT * 64;  // float4 units of one [M][D] packed activation
+        r.x = g->x; r.stats = g->stats; r.KB = KBD; r.MT = MT; r.n_chunks = nch;
+        r.tok_emb = g->tok_emb; r.pos_emb = g->pos_emb; r.tok = io.tok; r.tok_stride = io.tok_stride;
+        r.tok_use_pos = io.tok_use_pos; r.pos_dev = g->pos_dev; r.B = (int)B; r.K = D;
+        r.slabs = g->slabs; r.slab_stride = act;
+        // split factors (fixed per shape so that a role can be replayed on its own)
+        S_qkv = g->force_s[0] > 0 ? g->force_s[0] : 1;
+        S_proj = g->force_s[1] > 0 ? g->force_s[1] : split_for(D / 32, KBD);
+        S_fc2 = g->force_s[2] > 0 ? g->force_s[2] : ((MT % 2 == 0 && KBF >= 128) ? 4 : split_for(D / 32, KBF));
+    }
+    int split_for(int NT, int KB) const { return pick_split(MT % 2 == 0 ? NT * (MT / 2) : NT * MT, KB, 4); }
+    GemmArgs base() const {
         GemmArgs a{};
         a.MT = MT; a.B = (int)B; a.stats = g->stats; a.n_chunks = nch; a.K = D;
         a.pos_dev = g->pos_dev; a.D = D; a.H = g->H; a.hd = g->hd; a.Tmax = g->Tmax;
-        // QKV projection of the RAW residual stream as split-K slabs; LN1, bias and the KV-cache
-        // append are finished per (sequence, head) in the attention kernel's prologue
-        a.Wp = w.wqkv; a.Xp = g->x; a.bias = nullptr; a.c1 = nullptr; a.KB = KBD; a.NT = 3 * D / 32;
-        const long long act3 = 3 * act;
-        a.out_packed = g->qkv_slabs; a.slab_stride = act3;
-        const long long lstride = (long long)g->Bmax * g->H * g->Tmax * g->hd;
-        int S_qkv = 1;
-        g->span_begin(WMAR_T_QKV, st);
-        // measured: one slab (no K split across workgroups) beats every split for this shape --
-        // more, thinner workgroups per CU contend for the same L1 fill path
-        rc = gemm_split(a, &S_qkv, st, g->force_s[0] > 0 ? g->force_s[0] : 1);
+        return a;
+    }
+    int embed() {
+        g->span_begin(WMAR_T_EMBED, st);
+        hipLaunchKernelGGL((k_resid_stats<true, 0>), dim3(nch * MT), dim3(256), 0, st, r);
         g->span_end(st);
-        if (rc) return rc;
-        // attention
+        return launch_status("k_resid_stats<embed>");
+    }
+    // x += bias + sum of the S partial slabs; LN statistics of the new rows
+    int resid(const float* bias, int S) {
+        r.S = S; r.bias = bias;
+        g->span_begin(WMAR_T_RESID, st);
+        int rc = launch_resid(r, nch * MT, st);
+        g->span_end(st);
+        return rc;
+    }
+    // QKV projection of the RAW residual stream into slabs; LN1, bias and the KV-cache append are
+    // finished per (sequence, head) in the attention kernel's prologue.  Measured: one slab (no K
+    // split across workgroups) beats every split for this shape -- more, thinner workgroups per CU
+    // contend for the same L1 fill path.
+    int qkv(int l) {
+        GemmArgs a = base();
+        const LayerW& w = g->layers[l];
+        a.Wp = w.wqkv; a.Xp = g->x; a.KB = KBD; a.NT = 3 * D / 32;
+        a.out_packed = g->qkv_slabs; a.slab_stride = 3 * act;
+        int S = 1;
+        g->span_begin(WMAR_T_QKV, st);
+        int rc = gemm_split(a, &S, st, S_qkv);
+        g->span_end(st);
+        return rc;
+    }
+    int attn(int l) {
+        const LayerW& w = g->layers[l];
+        const long long lstride = (long long)g->Bmax * g->H * g->Tmax * g->hd;
         AttnArgs t{};
-        t.qkv_slabs = g->qkv_slabs; t.slab_stride = act3; t.S = S_qkv; t.stats = g->stats; t.n_chunks = nch; t.K = D;
+        t.qkv_slabs = g->qkv_slabs; t.slab_stride = 3 * act; t.S = S_qkv; t.stats = g->stats; t.n_chunks = nch; t.K = D;
         t.c1 = w.cqkv; t.bias = w.bqkv;
         t.kcache = g->kcache + l * lstride; t.vcache = g->vcache + l * lstride; t.y = g->y; t.pos_dev = g->pos_dev;
         t.D = D; t.H = g->H; t.Tmax = g->Tmax; t.MT = MT; t.scale = 1.0f / sqrtf((float)g->hd);
@@ -795,48 +813,67 @@ int enqueue_step(wmar_gpt* g, int64_t B, const StepIO& io, hipStream_t st) {
         else if (g->hd == 32) hipLaunchKernelGGL(k_attn_decode<32>, grid, dim3(64), lds, st, t);
         else hipLaunchKernelGGL(k_attn_decode<128>, grid, dim3(64), lds, st, t);
         g->span_end(st);
-        if ((rc = launch_status("k_attn_decode"))) return rc;
-        // proj (split-K partial slabs; bias + residual folded by the next k_resid_stats)
-        GemmArgs p = a;
-        p.Wp = w.wproj; p.Xp = g->y; p.bias = nullptr; p.c1 = nullptr; p.KB = KBD; p.NT = D / 32;
+        return launch_status("k_attn_decode");
+    }
+    // attention output projection (split-K slabs; bias + residual folded by the next resid())
+    int proj(int l) {
+        GemmArgs p = base();
+        p.Wp = g->layers[l].wproj; p.Xp = g->y; p.KB = KBD; p.NT = D / 32;
         p.out_packed = g->slabs; p.slab_stride = act;
-        int S_proj = 1;
+        int S = 1;
         g->span_begin(WMAR_T_PROJ, st);
-        rc = gemm_split(p, &S_proj, st, g->force_s[1]);
+        int rc = gemm_split(p, &S, st, S_proj);
         g->span_end(st);
-        if (rc) return rc;
-        r.slabs = g->slabs; r.slab_stride = act; r.S = S_proj; r.bias = w.bproj;
-        g->span_begin(WMAR_T_RESID, st);
-        rc = launch_resid(r, nch * MT, st);
-        g->span_end(st);
-        if (rc) return rc;
-        // LN2 -> FC1 (+bias, GELU) -> packed hidden
-        GemmArgs f = a;
+        return rc;
+    }
+    // LN2 -> FC1 (+bias, GELU) -> packed hidden
+    int fc1(int l) {
+        GemmArgs f = base();
+        const LayerW& w = g->layers[l];
         f.Wp = w.wfc1; f.Xp = g->x; f.bias = w.bfc1; f.c1 = w.cfc1; f.KB = KBD; f.NT = 4 * D / 32;
         f.out_packed = g->hbuf; f.slab_stride = 0;
         g->span_begin(WMAR_T_FC1, st);
-        rc = gemm_dispatch<EPI_GELU, true>(f, false, st);
+        int rc = gemm_dispatch<EPI_GELU, true>(f, false, st);
         g->span_end(st);
-        if (rc) return rc;
-        // FC2 (split-K partial slabs)
-        GemmArgs q = a;
-        q.Wp = w.wfc2; q.Xp = g->hbuf; q.bias = nullptr; q.c1 = nullptr; q.KB = KBF; q.NT = D / 32;
-        q.out_packed = g->slabs; q.slab_stride = act;
-        g->span_begin(WMAR_T_FC2, st);
-        rc = gemm_split(q, &S_prev, st, g->force_s[2] > 0 ? g->force_s[2] : (MT % 2 == 0 && KBF >= 128 ? 4 : 0));
-        g->span_end(st);
-        if (rc) return rc;
-        bias_prev = w.bfc2;
+        return rc;
     }
-    // ln_f -> head
-    GemmArgs hsd{};
-    hsd.MT = MT; hsd.B = (int)B; hsd.stats = g->stats; hsd.n_chunks = nch; hsd.K = D;
-    hsd.Wp = g->whead; hsd.Xp = g->x; hsd.KB = KBD; hsd.NT = g->V / 32;
-    hsd.bias = g->bhead; hsd.c1 = g->chead; hsd.logits = io.logits; hsd.V = g->V;
-    g->span_begin(WMAR_T_HEAD, st);
-    rc = gemm_dispatch<EPI_LOGITS, true>(hsd, false, st);
-    g->span_end(st);
-    return rc;
+    int fc2(int l) {
+        GemmArgs q = base();
+        q.Wp = g->layers[l].wfc2; q.Xp = g->hbuf; q.KB = KBF; q.NT = D / 32;
+        q.out_packed = g->slabs; q.slab_stride = act;
+        int S = 1;
+        g->span_begin(WMAR_T_FC2, st);
+        int rc = gemm_split(q, &S, st, S_fc2);
+        g->span_end(st);
+        return rc;
+    }
+    // ln_f -> vocabulary head
+    int head() {
+        GemmArgs h = base();
+        h.Wp = g->whead; h.Xp = g->x; h.KB = KBD; h.NT = g->V / 32;
+        h.bias = g->bhead; h.c1 = g->chead; h.logits = io.logits; h.V = g->V;
+        g->span_begin(WMAR_T_HEAD, st);
+        int rc = gemm_dispatch<EPI_LOGITS, true>(h, false, st);
+        g->span_end(st);
+        return rc;
+    }
+};
+
+int enqueue_step(wmar_gpt* g, int64_t B, const StepIO& io, hipStream_t st) {
+    StepPlan p(g, B, io, st);
+    int rc;
+    if ((rc = p.embed())) return rc;
+    for (int l = 0; l < g->L; ++l) {
+        if (l > 0 && (rc = p.resid(g->layers[l - 1].bfc2, p.S_fc2))) return rc;
+        if ((rc = p.qkv(l))) return rc;
+        if ((rc = p.attn(l))) return rc;
+        if ((rc = p.proj(l))) return rc;
+        if ((rc = p.resid(g->layers[l].bproj, p.S_proj))) return rc;
+        if ((rc = p.fc1(l))) return rc;
+        if ((rc = p.fc2(l))) return rc;
+    }
+    if ((rc = p.resid(g->layers[g->L - 1].bfc2, p.S_fc2))) return rc;
+    return p.head();
 }
 
 }  // namespace
@@ -941,6 +978,10 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
     if (rc == WMAR_OK) {
         // padded rows of the packed buffers must hold finite numbers
         hipError_t e = hipMemsetAsync(g->x, 0, Mpad * D * 4, st);
+        if (e == hipSuccess) e = hipMemsetAsync(g->kcache, 0, kv * 4, st);
+        if (e == hipSuccess) e = hipMemsetAsync(g->vcache, 0, kv * 4, st);
+        if (e == hipSuccess) e = hipMemsetAsync(g->hbuf, 0, Mpad * 4 * D * 4, st);
+        if (e == hipSuccess) e = hipMemsetAsync(g->past, 0, (size_t)g->Bmax * (g->Tmax + 1) * 8, st);
         if (e == hipSuccess) e = hipMemsetAsync(g->y, 0, Mpad * D * 4, st);
         if (e == hipSuccess) e = hipMemsetAsync(g->qbuf, 0, Mpad * D * 4, st);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->cap_stream, hipStreamNonBlocking);
@@ -966,6 +1007,45 @@ int wmar_gpt_decode_step(wmar_gpt* g, const int64_t* tok_dev, int64_t B, int32_t
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, g->pos_dev, (int)pos);
     StepIO io{(const long long*)tok_dev, 1, 0, logits_dev};
     return enqueue_step(g, B, io, st);
+}
+
+int wmar_gpt_profile_role(wmar_gpt* g, int32_t role, int64_t B, int32_t kv_len, int32_t iters, void* stream,
+                          double* avg_us) {
+    WMAR_REQUIRE(g && avg_us && iters > 0, "profile_role: bad argument");
+    WMAR_REQUIRE(B >= 1 && B <= g->Bmax, "profile_role: batch outside 1..%d", g->Bmax);
+    WMAR_REQUIRE(kv_len >= 1 && kv_len <= g->Tmax, "profile_role: kv_len outside 1..%d", g->Tmax);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, g->pos_dev, (int)kv_len - 1);
+    StepIO io{g->past, (long long)g->Tmax + 1, 0, g->logits};
+    StepPlan p(g, B, io, st);
+    auto one = [&](int it) -> int {
+        const int l = it % g->L;
+        switch (role) {
+            case WMAR_T_EMBED: return p.embed();
+            case WMAR_T_QKV: return p.qkv(l);
+            case WMAR_T_ATTN: return p.attn(l);
+            case WMAR_T_PROJ: return p.proj(l);
+            case WMAR_T_RESID: return p.resid(g->layers[l].bproj, p.S_proj);
+            case WMAR_T_FC1: return p.fc1(l);
+            case WMAR_T_FC2: return p.fc2(l);
+            case WMAR_T_HEAD: return p.head();
+            default: set_error("profile_role: unknown role %d", role); return WMAR_EINVAL;
+        }
+    };
+    const bool was = g->span_on;
+    g->span_on = false;
+    int rc = WMAR_OK;
+    for (int i = 0; i < 3 && rc == WMAR_OK; ++i) rc = one(i);           // warm-up
+    if (rc == WMAR_OK && hipEventRecord(g->ev0, st) != hipSuccess) rc = WMAR_EHIP;
+    for (int i = 0; i < iters && rc == WMAR_OK; ++i) rc = one(i + 3);
+    if (rc == WMAR_OK && hipEventRecord(g->ev1, st) != hipSuccess) rc = WMAR_EHIP;
+    g->span_on = was;
+    if (rc) return rc;
+    WMAR_HIP_CHECK(hipEventSynchronize(g->ev1));
+    float ms = 0.f;
+    WMAR_HIP_CHECK(hipEventElapsedTime(&ms, g->ev0, g->ev1));
+    *avg_us = (double)ms * 1000.0 / iters;
+    return WMAR_OK;
 }
 
 int wmar_gpt_set_timing(wmar_gpt* g, int32_t enabled) { if (!g) return WMAR_EINVAL; g->timing = enabled; return WMAR_OK; }

@@ -80,6 +80,14 @@ class GPTEngine:
                 _lib.stream_ptr(self.device)))
         return (out, trace) if trace_logits else out
 
+    def profile_role(self, role: str, B: int, kv_len: int = 128, iters: int = 96) -> float:
+        """Average microseconds per launch of one role's kernel replayed back to back (HIP events)."""
+        out = C.c_double()
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.wmar_gpt_profile_role(self._h, self.T_CLASSES.index(role), B, kv_len, iters,
+                                                     _lib.stream_ptr(self.device), C.byref(out)))
+        return out.value
+
     def set_timing(self, on: bool):
         self._L.wmar_gpt_set_timing(self._h, 1 if on else 0)
 
