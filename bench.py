@@ -190,8 +190,17 @@ def main():
                   "fc2": "k_gemm<2,4,EPI_PACKED> 6144->1536 split-K (FC2)",
                   "proj": "k_gemm<2,4,EPI_PACKED> 1536->1536 split-K (proj)",
                   "head": "k_gemm<2,4,EPI_LOGITS,LN> 1536->16384 (head)"}[dom]
+        # HBM bytes per launch of that kernel from the committed PMC passes (profiles/pmc_fc1.json:
+        # separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction); null for other kernels
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_fc1.json")))
+            if dom == "fc1":
+                traffic = pmc["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TF, 4), "traffic": None, "kernel": kernel,
+                    "frac": round(achieved / PEAK_F32_MFMA_TF, 4), "traffic": traffic, "kernel": kernel,
                     "avg_us": round(avg_us[dom], 2), "launches_per_step": per_step[dom],
                     "flop_per_launch": flops[dom],
                     "share_of_decode_step": round(share[dom] / sum(share.values()), 3)}

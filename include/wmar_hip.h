@@ -135,7 +135,8 @@ int wmar_gpt_decode_step(wmar_gpt* g, const int64_t* tok_dev, int64_t B, int32_t
  * (decode step + fused watermark/sampling + position advance; the position lives in
  * device memory).  cond_dev int64 [B] (the class token), q_dev float [steps, B, V] (noise for
  * every step, see wmar_sample_fused), tokens_out_dev int64 [B, steps].
- * logits_trace_dev (nullable): float [steps, B, V], raw model logits per step. */
+ * logits_trace_dev (nullable): float [steps, B, V], raw model logits per step.
+ * Asynchronous: everything is ordered on `stream`; one generate per engine at a time. */
 typedef struct wmar_sample_params {
     float temperature;
     int32_t top_k;  /* <= 0: off */
