@@ -244,7 +244,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
     const int mt0 = mg * MTW;
     const int slices = a.S * NW;
     const int sl = s * NW + w;
-    const int kb0 = (int)((long long)sl * a.KB / slices), kb1 = (int)((long long)(sl + 1) * a.KB / slices);
+    // 32-bit index math (there is no integer divide instruction: 64-bit division is ~10x dearer)
+    const int kb0 = (int)((unsigned)sl * (unsigned)a.KB / (unsigned)slices);
+    const int kb1 = (int)((unsigned)(sl + 1) * (unsigned)a.KB / (unsigned)slices);
     const int half = lane >> 5;
 #ifdef WMAR_GEMM_TRACE
     unsigned long long tr0 = __builtin_amdgcn_s_memtime(), tr1 = 0, tr2 = 0;

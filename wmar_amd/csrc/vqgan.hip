@@ -572,6 +572,8 @@ bool in_attn_res(const wmar_vq_config& c, int res) {
     return false;
 }
 
+static bool vq_trace() { static int v = -1; if (v < 0) { const char* e = getenv("WMAR_VQ_TRACE"); v = e ? atoi(e) : 0; } return v != 0; }
+
 int run_conv(const ConvW& c, const float* in, float* out, const float* res, int B, int Hs, int Ws, int stride, int up,
              hipStream_t st) {
     ConvArgs a{};
@@ -588,9 +590,19 @@ int run_conv(const ConvW& c, const float* in, float* out, const float* res, int 
     const int COT = c.CT >= 4 ? 4 : (c.CT >= 2 ? 2 : 1);
     const int cgroups = (c.CT + COT - 1) / COT;
     const unsigned grid = (unsigned)((long long)B * cgroups * a.tiles_x * a.tiles_y);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (vq_trace()) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
     if (COT == 4) hipLaunchKernelGGL(k_conv<4>, dim3(grid), dim3(256), lds, st, a);
     else if (COT == 2) hipLaunchKernelGGL(k_conv<2>, dim3(grid), dim3(128), lds, st, a);
     else hipLaunchKernelGGL(k_conv<1>, dim3(grid), dim3(64), lds, st, a);
+    if (vq_trace()) {
+        (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
+        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+        double fl = 2.0 * B * a.Ho * a.Wo * (double)c.cout * c.cin * c.ks * c.ks;
+        fprintf(stderr, "conv %4d->%4d k%d s%d up%d %3dx%-3d  %8.1f us  %6.1f TF/s  grid %u\n", c.cin, c.cout, c.ks, stride, up, a.Ho, a.Wo,
+                ms * 1e3, fl / (ms * 1e-3) * 1e-12, grid);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
     return launch_status("k_conv");
 }
 

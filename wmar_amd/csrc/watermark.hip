@@ -113,6 +113,10 @@ __device__ __forceinline__ int scan_hist(const unsigned long long* hist, unsigne
     return ASC_MASS ? bucket : 255 - bucket;
 }
 
+// EPT > 0: the whole row lives in registers (EPT values per thread, V <= EPT*1024) and every pass
+// after the first runs out of registers -- with the row in memory each of the ~13 passes is a chain
+// of dependent L2 round trips (measured 75 us/step).  EPT == 0: generic path through `scratch`.
+template <int EPT>
 __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
     __shared__ unsigned long long hist[256];
     __shared__ unsigned long long red[SAMP_WAVES];
@@ -134,16 +138,49 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
     float* trace = a.trace ? a.trace + (step * a.B + b) * V : nullptr;
     const float T = a.temperature;
     const float delta = a.wm.delta;
+    float xr[EPT > 0 ? EPT : 1];
+
+#define WMAR_FOR_ROW(BODY)                                                                   \
+    if (EPT > 0) {                                                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < (EPT > 0 ? EPT : 1); ++i_) {                \
+            const long long v = tid + (long long)i_ * SAMP_THREADS;                          \
+            if (v < V) { const float xv = xr[i_]; BODY }                                     \
+        }                                                                                    \
+    } else {                                                                                 \
+        for (long long v = tid; v < V; v += SAMP_THREADS) { const float xv = x[v]; BODY }    \
+    }
 
     // P0: bias, temperature, row max
     uint32_t kmax = 0;
-    for (long long v = tid; v < V; v += SAMP_THREADS) {
-        float xv = lg[v];
-        if (trace) trace[v] = xv;
-        if (grow && ((grow[v >> 5] >> (v & 31)) & 1u)) xv = xv + delta;
-        xv = xv / T;
-        x[v] = xv;
-        kmax = max(kmax, wmar_f32_key(xv));
+    if (EPT > 0) {
+        float lv[EPT > 0 ? EPT : 1];
+#pragma unroll
+        for (int i = 0; i < (EPT > 0 ? EPT : 1); ++i) {
+            const long long v = tid + (long long)i * SAMP_THREADS;
+            lv[i] = v < V ? lg[v] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < (EPT > 0 ? EPT : 1); ++i) {
+            const long long v = tid + (long long)i * SAMP_THREADS;
+            if (v < V) {
+                float xv = lv[i];
+                if (trace) trace[v] = xv;
+                if (grow && ((grow[v >> 5] >> (v & 31)) & 1u)) xv = xv + delta;
+                xv = xv / T;
+                x[v] = xv;
+                xr[i] = xv;
+                kmax = max(kmax, wmar_f32_key(xv));
+            }
+        }
+    } else {
+        for (long long v = tid; v < V; v += SAMP_THREADS) {
+            float xv = lg[v];
+            if (trace) trace[v] = xv;
+            if (grow && ((grow[v >> 5] >> (v & 31)) & 1u)) xv = xv + delta;
+            xv = xv / T;
+            x[v] = xv;
+            kmax = max(kmax, wmar_f32_key(xv));
+        }
     }
     kmax = block_max_u32(kmax, red);
     const float m = wmar_key_f32(kmax);
@@ -157,9 +194,35 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
         for (int pass = 3; pass >= 0; --pass) {
             for (int i = tid; i < 256; i += SAMP_THREADS) hist[i] = 0;
             __syncthreads();
-            for (long long v = tid; v < V; v += SAMP_THREADS) {
-                uint32_t k = wmar_f32_key(x[v]);
-                if ((k & mask) == prefix) atomicAdd(&hist[(k >> (8 * pass)) & 255u], 1ull);
+            if (pass == 3) {
+                // The top byte (sign + 7 exponent bits) takes a handful of values: per-lane LDS
+                // atomics on the same bucket serialise, so each wave first counts its lanes per
+                // distinct digit (ballot) and issues ONE add per digit.
+                for (int i_ = 0; i_ < (int)((V + SAMP_THREADS - 1) / SAMP_THREADS); ++i_) {
+                    const long long v = tid + (long long)i_ * SAMP_THREADS;
+                    bool active = v < V;
+                    float xv = 0.f;
+                    if (EPT > 0) {
+#pragma unroll
+                        for (int j = 0; j < (EPT > 0 ? EPT : 1); ++j) if (j == i_) xv = xr[j];
+                    } else if (active) {
+                        xv = x[v];
+                    }
+                    const uint32_t d = active ? (wmar_f32_key(xv) >> 24) : 0u;
+                    unsigned long long todo = __ballot(active);
+                    while (todo) {
+                        const int leader = __ffsll((long long)todo) - 1;
+                        const uint32_t dl = (uint32_t)__shfl((int)d, leader);
+                        const unsigned long long same = __ballot(active && d == dl);
+                        if ((tid & 63) == leader) atomicAdd(&hist[dl], (unsigned long long)__popcll(same));
+                        todo &= ~same;
+                    }
+                }
+            } else {
+                WMAR_FOR_ROW({
+                    const uint32_t k = wmar_f32_key(xv);
+                    if ((k & mask) == prefix) atomicAdd(&hist[(k >> (8 * pass)) & 255u], 1ull);
+                })
             }
             __syncthreads();
             if (tid < 64) {
@@ -182,10 +245,9 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
     long long bidx = 0;
     if (a.use_top_p) {
         unsigned long long S = 0;
-        for (long long v = tid; v < V; v += SAMP_THREADS) {
-            float xv = x[v];
+        WMAR_FOR_ROW({
             if (wmar_f32_key(xv) >= thr_key) S += wmar_fx(wmar_expf(xv - m));
-        }
+        })
         S = block_sum_u64(S, red);
         const float Sf = wmar_fx_to_f32(S);
         const float thr = a.top_p_thr;
@@ -195,12 +257,11 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
         for (int pass = 3; pass >= 0 && !all_pass; --pass) {
             for (int i = tid; i < 256; i += SAMP_THREADS) hist[i] = 0;
             __syncthreads();
-            for (long long v = tid; v < V; v += SAMP_THREADS) {
-                float xv = x[v];
-                uint32_t k = wmar_f32_key(xv);
+            WMAR_FOR_ROW({
+                const uint32_t k = wmar_f32_key(xv);
                 if (k >= thr_key && (k & mask) == prefix)
                     atomicAdd(&hist[(k >> (8 * pass)) & 255u], wmar_fx(wmar_expf(xv - m) / Sf));
-            }
+            })
             __syncthreads();
             if (tid < 64) {
                 unsigned long long below;
@@ -220,18 +281,17 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
             // ties at the boundary value: refine on the index (ascending), 8 bits at a time
             bkey = prefix;
             unsigned long long cnt = 0;
-            for (long long v = tid; v < V; v += SAMP_THREADS) cnt += (wmar_f32_key(x[v]) == bkey);
+            WMAR_FOR_ROW({ cnt += (wmar_f32_key(xv) == bkey); })
             cnt = block_sum_u64(cnt, red);
             if (cnt > 1) {
                 uint32_t ipre = 0, imask = 0;
                 for (int pass = 3; pass >= 0; --pass) {
                     for (int i = tid; i < 256; i += SAMP_THREADS) hist[i] = 0;
                     __syncthreads();
-                    for (long long v = tid; v < V; v += SAMP_THREADS) {
-                        float xv = x[v];
+                    WMAR_FOR_ROW({
                         if (wmar_f32_key(xv) == bkey && (((uint32_t)v) & imask) == ipre)
                             atomicAdd(&hist[(((uint32_t)v) >> (8 * pass)) & 255u], wmar_fx(wmar_expf(xv - m) / Sf));
-                    }
+                    })
                     __syncthreads();
                     if (tid < 64) {
                         unsigned long long below;
@@ -253,32 +313,54 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
             // everything satisfies cum <= thr: only the last element of the order survives
             bkey = kmax;
             uint32_t imax = 0;
-            for (long long v = tid; v < V; v += SAMP_THREADS)
-                if (wmar_f32_key(x[v]) == kmax) imax = max(imax, (uint32_t)v);
+            WMAR_FOR_ROW({ if (wmar_f32_key(xv) == kmax) imax = max(imax, (uint32_t)v); })
             bidx = (long long)block_max_u32(imax, red);
         }
     }
 
     // final softmax over the kept set + exponential race argmax(p / q), first index on ties
     unsigned long long S2 = 0;
-    for (long long v = tid; v < V; v += SAMP_THREADS) {
-        float xv = x[v];
-        uint32_t k = wmar_f32_key(xv);
-        bool kept = k >= thr_key && (k > bkey || (k == bkey && v >= bidx));
+    WMAR_FOR_ROW({
+        const uint32_t k = wmar_f32_key(xv);
+        const bool kept = k >= thr_key && (k > bkey || (k == bkey && v >= bidx));
         if (kept) S2 += wmar_fx(wmar_expf(xv - m));
-    }
+    })
     S2 = block_sum_u64(S2, red);
     const float Sf2 = wmar_fx_to_f32(S2);
     float best = -INFINITY;
     int besti = 0;
-    for (long long v = tid; v < V; v += SAMP_THREADS) {
-        float xv = x[v];
-        uint32_t k = wmar_f32_key(xv);
-        bool kept = k >= thr_key && (k > bkey || (k == bkey && v >= bidx));
-        float e = kept ? wmar_expf(xv - m) : 0.0f;
-        float r = (e / Sf2) / q[v];
-        if (r > best) { best = r; besti = (int)v; }
+    float qv[EPT > 0 ? EPT : 1];
+    if (EPT > 0) {
+#pragma unroll
+        for (int i = 0; i < (EPT > 0 ? EPT : 1); ++i) {
+            const long long v = tid + (long long)i * SAMP_THREADS;
+            qv[i] = v < V ? q[v] : 1.f;
+        }
     }
+    if (EPT > 0) {
+#pragma unroll
+        for (int i = 0; i < (EPT > 0 ? EPT : 1); ++i) {
+            const long long v = tid + (long long)i * SAMP_THREADS;
+            if (v < V) {
+                const float xv = xr[i];
+                const uint32_t k = wmar_f32_key(xv);
+                const bool kept = k >= thr_key && (k > bkey || (k == bkey && v >= bidx));
+                const float e = kept ? wmar_expf(xv - m) : 0.0f;
+                const float r = (e / Sf2) / qv[i];
+                if (r > best) { best = r; besti = (int)v; }
+            }
+        }
+    } else {
+        for (long long v = tid; v < V; v += SAMP_THREADS) {
+            const float xv = x[v];
+            const uint32_t k = wmar_f32_key(xv);
+            const bool kept = k >= thr_key && (k > bkey || (k == bkey && v >= bidx));
+            const float e = kept ? wmar_expf(xv - m) : 0.0f;
+            const float r = (e / Sf2) / q[v];
+            if (r > best) { best = r; besti = (int)v; }
+        }
+    }
+#undef WMAR_FOR_ROW
     for (int o = 32; o > 0; o >>= 1) {
         float ob = __shfl_xor(best, o);
         int oi = __shfl_xor(besti, o);
@@ -394,7 +476,9 @@ __global__ __launch_bounds__(256) void k_detect(DetArgs a) {
 
 // Launch helper shared with the generation graph (gpt.hip).
 int launch_sample_fused(const SampArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_sample_fused, dim3((unsigned)a.B), dim3(SAMP_THREADS), 0, st, a);
+    if (a.V <= 16ll * SAMP_THREADS) hipLaunchKernelGGL(k_sample_fused<16>, dim3((unsigned)a.B), dim3(SAMP_THREADS), 0, st, a);
+    else if (a.V <= 64ll * SAMP_THREADS) hipLaunchKernelGGL(k_sample_fused<64>, dim3((unsigned)a.B), dim3(SAMP_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(k_sample_fused<0>, dim3((unsigned)a.B), dim3(SAMP_THREADS), 0, st, a);
     return launch_status("k_sample_fused");
 }
 
