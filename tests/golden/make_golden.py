@@ -36,6 +36,108 @@ def _stubs(d):
     open(os.path.join(d, "torchvision", "transforms", "__init__.py"), "w").write(
         "class PILToTensor:\n    pass\nfrom . import functional\n")
     open(os.path.join(d, "torchvision", "transforms", "functional.py"), "w").write("")
+    # timm.layers.Mlp (third-party, absent here): its published semantics fc1 -> act -> drop -> norm -> fc2 -> drop
+    os.makedirs(os.path.join(d, "timm", "layers"))
+    open(os.path.join(d, "timm", "__init__.py"), "w").write("")
+    open(os.path.join(d, "timm", "layers", "__init__.py"), "w").write(
+        "import torch.nn as nn\n"
+        "class Mlp(nn.Module):\n"
+        "    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, norm_layer=None,\n"
+        "                 bias=True, drop=0.0, use_conv=False):\n"
+        "        super().__init__()\n"
+        "        out_features = out_features or in_features\n"
+        "        hidden_features = hidden_features or in_features\n"
+        "        self.fc1 = nn.Linear(in_features, hidden_features, bias=bias)\n"
+        "        self.act = act_layer()\n"
+        "        self.drop1 = nn.Dropout(drop)\n"
+        "        self.norm = norm_layer(hidden_features) if norm_layer is not None else nn.Identity()\n"
+        "        self.fc2 = nn.Linear(hidden_features, out_features, bias=bias)\n"
+        "        self.drop2 = nn.Dropout(drop)\n"
+        "    def forward(self, x):\n"
+        "        return self.drop2(self.fc2(self.norm(self.drop1(self.act(self.fc1(x))))))\n")
+
+
+def rar_vectors(args, synth, wms, rs):
+    """RAR generator + MaskGIT-VQGAN tokenizer vectors."""
+    import torch
+    from deps.rar.modeling.modules.maskgit_vqgan import Decoder, Encoder, VectorQuantizer
+    from deps.rar.modeling.rar import RAR
+
+    class AD(dict):
+        def __getattr__(self, k):
+            v = self[k]
+            return AD(v) if isinstance(v, dict) else v
+
+        def get(self, k, d=None):
+            return dict.get(self, k, d)
+
+    out = {}
+    rcfg = synth.RARConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
+                           image_seq_len=16, codebook_size=1024, condition_num_classes=1000)
+    cfg = AD(model=dict(vq_model=dict(codebook_size=1024),
+                        generator=dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
+                                       image_seq_len=16, condition_num_classes=1000, dropout=0.0, attn_drop=0.0)))
+    sd = synth.synth_rar_state(rcfg, seed=2, logit_scale=30.0)
+    gen = RAR(cfg).eval()
+    gen.load_state_dict(sd, strict=True)   # pins the checkpoint key layout (attn_mask is non-persistent)
+    gen.set_random_ratio(0)
+    wm = wms["rar"]
+    wm.delta = 2.0
+    cond = torch.tensor([[3], [977], [0], [512]], dtype=torch.long)
+    rec = []
+    orig = gen.forward_fn
+
+    def spy(ids, condition, **kw):
+        r = orig(ids, condition, **kw)
+        rec.append(r[:, -1].detach().clone().numpy())
+        return r
+
+    gen.forward_fn = spy
+    torch.manual_seed(21)
+    toks = gen.generate(condition=cond, guidance_scale=4.0, guidance_scale_pow=0.0, randomize_temperature=1.0,
+                        logit_processor=wm.spawn_logit_processor())
+    out["rar_cond"] = cond.view(-1).numpy()
+    out["rar_tokens_wm"] = toks.numpy()
+    out["rar_logits"] = np.stack(rec)[:5]           # [5, 2B, V] cond rows then uncond rows, steps 0..4
+    rec.clear()
+    torch.manual_seed(21)
+    out["rar_tokens_nowm"] = gen.generate(condition=cond, guidance_scale=4.0, guidance_scale_pow=0.0,
+                                          randomize_temperature=1.0).numpy()
+    rec.clear()
+    torch.manual_seed(21)
+    out["rar_tokens_pow"] = gen.generate(condition=cond, guidance_scale=3.0, guidance_scale_pow=1.5,
+                                         randomize_temperature=0.9, logit_processor=wm.spawn_logit_processor()).numpy()
+    gen.forward_fn = orig
+    torch.manual_seed(21)
+    torch.rand(4, 1)   # the label-drop mask draw of preprocess_condition (rar.py:305) precedes the sampling noise
+    out["rar_q"] = np.stack([torch.empty(4, 1024).exponential_(1).numpy() for _ in range(16)])[:5]
+    out["rar_pvals_wm"] = wm.detect(toks).numpy()
+
+    # tokenizer
+    mcfg = synth.MaskgitVQConfig(hidden_channels=32, channel_mult=(1, 2, 2), num_res_blocks=1, resolution=32, z_channels=16,
+                                 num_embeddings=256)
+    msd = synth.synth_maskgit_state(mcfg, seed=4)
+    tc = AD(channel_mult=list(mcfg.channel_mult), num_resolutions=mcfg.num_resolutions, dropout=0.0,
+            hidden_channels=mcfg.hidden_channels, num_channels=3, num_res_blocks=mcfg.num_res_blocks,
+            resolution=mcfg.resolution, z_channels=mcfg.z_channels)
+    enc, dec = Encoder(tc).eval(), Decoder(tc).eval()
+    vq = VectorQuantizer(mcfg.num_embeddings, mcfg.z_channels, 0.25).eval()
+    enc.load_state_dict({k[8:]: v for k, v in msd.items() if k.startswith("encoder.")}, strict=True)
+    dec.load_state_dict({k[8:]: v for k, v in msd.items() if k.startswith("decoder.")}, strict=True)
+    vq.load_state_dict({"embedding.weight": msd["quantize.embedding.weight"]}, strict=True)
+    S = mcfg.codes_size
+    codes = torch.from_numpy(rs.randint(0, mcfg.num_embeddings, size=(2, S * S)).astype(np.int64))
+    with torch.no_grad():
+        img01 = torch.clamp(dec(vq.get_codebook_entry(codes)), 0.0, 1.0)          # titok.py:81-85
+        img = torch.clamp(img01 * 2.0 - 1.0, -1.0, 1.0)                            # rar_wrapper.py:112-114
+        h = enc((img + 1.0) / 2.0)                                                  # rar_wrapper.py:124-125
+        _, idx, _ = vq(h)
+    out["mg_codes"] = codes.numpy()
+    out["mg_images"] = img.numpy()
+    out["mg_prequant"] = h.permute(0, 2, 3, 1).reshape(-1, mcfg.z_channels).numpy()
+    out["mg_codes_roundtrip"] = idx.view(2, -1).numpy()
+    np.savez_compressed(os.path.join(HERE, "rar_vectors.npz"), **out)
+    print("wrote rar_vectors.npz", os.path.getsize(os.path.join(HERE, "rar_vectors.npz")), "bytes")
 
 
 def main():
@@ -262,6 +364,7 @@ def main():
     out["vq_prequant"] = h.permute(0, 2, 3, 1).reshape(-1, vcfg.embed_dim).numpy()
     out["vq_codes_roundtrip"] = codes2.numpy()
 
+    rar_vectors(args, synth, wms, rs)
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     sz = os.path.getsize(os.path.join(HERE, "reference_vectors.npz"))
     print("wrote reference_vectors.npz", sz, "bytes; key_kat.json")

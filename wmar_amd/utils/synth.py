@@ -266,3 +266,169 @@ def synth_vq_state_fast(cfg: VQConfig, seed: int = 0, device="cuda"):
             t = (torch.rand(shp, generator=g, device=device) * 2.0 - 1.0) * (3.0 / fan_in) ** 0.5
         out[k] = t
     return out
+
+
+# ----------------------------------------------------------------------------- RAR
+@dataclasses.dataclass
+class RARConfig:
+    """deps/rar/modeling/rar.py:179-250 (dims: wmar/models/rar_wrapper.py:43-52, rar.yaml)."""
+    hidden_size: int = 1280
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 16
+    intermediate_size: int = 5120
+    image_seq_len: int = 256
+    codebook_size: int = 1024
+    condition_num_classes: int = 1000
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+    @property
+    def n_embeddings(self) -> int:
+        return self.codebook_size + 1 + self.condition_num_classes + 1
+
+    @property
+    def none_condition_id(self) -> int:
+        return self.condition_num_classes + self.codebook_size + 1
+
+
+@dataclasses.dataclass
+class MaskgitVQConfig:
+    """deps/rar/modeling/titok.py:44-56 (PretrainedTokenizer) / maskgit_vqgan.py."""
+    hidden_channels: int = 128
+    channel_mult: Tuple[int, ...] = (1, 1, 2, 2, 4)
+    num_res_blocks: int = 2
+    resolution: int = 256
+    num_channels: int = 3
+    z_channels: int = 256
+    num_embeddings: int = 1024
+
+    @property
+    def num_resolutions(self) -> int:
+        return len(self.channel_mult)
+
+    @property
+    def codes_size(self) -> int:
+        return self.resolution // (2 ** (self.num_resolutions - 1))
+
+
+RAR_XL = RARConfig()
+MASKGIT_VQ = MaskgitVQConfig()
+
+
+def rar_shapes(cfg: RARConfig) -> Dict[str, Tuple[int, ...]]:
+    d, L, hd = cfg.hidden_size, cfg.image_seq_len, cfg.head_dim
+    s: Dict[str, Tuple[int, ...]] = {"cls_token": (1, 1, d)}
+    for i in range(cfg.num_hidden_layers):
+        p = f"blocks.{i}."
+        s[p + "norm1.weight"] = (d,); s[p + "norm1.bias"] = (d,)
+        s[p + "attn.qkv.weight"] = (3 * d, d); s[p + "attn.qkv.bias"] = (3 * d,)
+        s[p + "attn.q_norm.weight"] = (hd,); s[p + "attn.q_norm.bias"] = (hd,)
+        s[p + "attn.k_norm.weight"] = (hd,); s[p + "attn.k_norm.bias"] = (hd,)
+        s[p + "attn.proj.weight"] = (d, d); s[p + "attn.proj.bias"] = (d,)
+        s[p + "norm2.weight"] = (d,); s[p + "norm2.bias"] = (d,)
+        s[p + "mlp.fc1.weight"] = (cfg.intermediate_size, d); s[p + "mlp.fc1.bias"] = (cfg.intermediate_size,)
+        s[p + "mlp.fc2.weight"] = (d, cfg.intermediate_size); s[p + "mlp.fc2.bias"] = (d,)
+        s[p + "adaLN_modulation.1.weight"] = (6 * d, d); s[p + "adaLN_modulation.1.bias"] = (6 * d,)
+    s["embeddings.weight"] = (cfg.n_embeddings, d)
+    s["pos_embed"] = (1, L + 1024, d)
+    s["target_aware_pos_embed"] = (1, L + 1024, d)
+    s["timesteps_embeddings"] = (1, L + 100, d)
+    s["adaln_before_head.adaLN_modulation.1.weight"] = (2 * d, d)
+    s["adaln_before_head.adaLN_modulation.1.bias"] = (2 * d,)
+    s["lm_head.weight"] = (cfg.codebook_size, d)
+    s["lm_head.bias"] = (cfg.codebook_size,)
+    return s
+
+
+def _mres(s, p, cin, cout):
+    s[p + "norm1.weight"] = (cin,); s[p + "norm1.bias"] = (cin,)
+    s[p + "conv1.weight"] = (cout, cin, 3, 3)
+    s[p + "norm2.weight"] = (cout,); s[p + "norm2.bias"] = (cout,)
+    s[p + "conv2.weight"] = (cout, cout, 3, 3)
+    if cin != cout:
+        s[p + "nin_shortcut.weight"] = (cout, cout, 1, 1)   # applied to the block OUTPUT (maskgit_vqgan.py:69-87)
+
+
+def maskgit_shapes(cfg: MaskgitVQConfig) -> Dict[str, Tuple[int, ...]]:
+    s: Dict[str, Tuple[int, ...]] = {}
+    hc, mult, R = cfg.hidden_channels, cfg.channel_mult, cfg.num_resolutions
+    s["encoder.conv_in.weight"] = (hc, cfg.num_channels, 3, 3)
+    in_mult = (1,) + tuple(mult)
+    for lvl in range(R):
+        bi, bo = hc * in_mult[lvl], hc * mult[lvl]
+        for b in range(cfg.num_res_blocks):
+            _mres(s, f"encoder.down.{lvl}.block.{b}.", bi, bo)
+            bi = bo
+    mid = hc * mult[-1]
+    for b in range(cfg.num_res_blocks):
+        _mres(s, f"encoder.mid.{b}.", mid, mid)
+    s["encoder.norm_out.weight"] = (mid,); s["encoder.norm_out.bias"] = (mid,)
+    s["encoder.conv_out.weight"] = (cfg.z_channels, mid, 1, 1); s["encoder.conv_out.bias"] = (cfg.z_channels,)
+    s["decoder.conv_in.weight"] = (mid, cfg.z_channels, 3, 3); s["decoder.conv_in.bias"] = (mid,)
+    for b in range(cfg.num_res_blocks):
+        _mres(s, f"decoder.mid.{b}.", mid, mid)
+    for lvl in range(R):
+        bi = hc * mult[-1] if lvl == R - 1 else hc * mult[lvl + 1]
+        bo = hc * mult[lvl]
+        for b in range(cfg.num_res_blocks):
+            _mres(s, f"decoder.up.{lvl}.block.{b}.", bi, bo)
+            bi = bo
+        if lvl != 0:
+            s[f"decoder.up.{lvl}.upsample_conv.weight"] = (bo, bo, 3, 3)
+            s[f"decoder.up.{lvl}.upsample_conv.bias"] = (bo,)
+    s["decoder.norm_out.weight"] = (hc * mult[0],); s["decoder.norm_out.bias"] = (hc * mult[0],)
+    s["decoder.conv_out.weight"] = (cfg.num_channels, hc * mult[0], 3, 3); s["decoder.conv_out.bias"] = (cfg.num_channels,)
+    s["quantize.embedding.weight"] = (cfg.num_embeddings, cfg.z_channels)
+    return s
+
+
+def _fill_rar(shapes, gen, device, logit_scale):
+    out = {}
+    for k, shp in shapes.items():
+        leaf = k.rsplit(".", 1)[-1]
+        is_norm = ("norm" in k) and leaf in ("weight", "bias")
+        if is_norm:
+            t = torch.randn(shp, generator=gen, device=gen.device) * 0.1
+            if leaf == "weight":
+                t = t + 1.0
+        elif leaf == "bias":
+            t = torch.randn(shp, generator=gen, device=gen.device) * 0.02
+        else:
+            t = torch.randn(shp, generator=gen, device=gen.device) * 0.02
+            if k == "lm_head.weight":
+                t = t * logit_scale
+            if "adaLN_modulation" in k:
+                t = t * 2.0   # the reference zero-inits these; non-zero so that the modulation path is exercised
+        out[k] = t.to(torch.float32).to(device)
+    return out
+
+
+def synth_rar_state(cfg: RARConfig, seed: int = 0, device="cpu", logit_scale: float = 1.0, gen_device="cpu"):
+    g = torch.Generator(device=gen_device)
+    g.manual_seed(seed + 4242)
+    return _fill_rar(rar_shapes(cfg), g, device, logit_scale)
+
+
+def synth_maskgit_state(cfg: MaskgitVQConfig, seed: int = 0, device="cpu", gen_device="cpu"):
+    g = torch.Generator(device=gen_device)
+    g.manual_seed(seed + 991)
+    out = {}
+    for k, shp in maskgit_shapes(cfg).items():
+        leaf = k.rsplit(".", 1)[-1]
+        if "norm" in k:
+            t = torch.randn(shp, generator=g, device=gen_device) * 0.1
+            if leaf == "weight":
+                t = t + 1.0
+        elif leaf == "bias":
+            t = torch.randn(shp, generator=g, device=gen_device) * 0.02
+        elif k == "quantize.embedding.weight":
+            t = torch.rand(shp, generator=g, device=gen_device) * 2.0 - 1.0
+        else:
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            t = (torch.rand(shp, generator=g, device=gen_device) * 2.0 - 1.0) * (3.0 / fan_in) ** 0.5
+        out[k] = t.to(torch.float32).to(device)
+    return out
