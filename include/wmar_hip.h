@@ -171,6 +171,41 @@ int wmar_gpt_profile_role(wmar_gpt* g, int32_t role, int64_t B, int32_t kv_len, 
 /* total_us[c], calls[c] for each class; *step_ms = average wall time of one decode step (any mode). */
 int wmar_gpt_get_timing(wmar_gpt* g, double* total_us, int64_t* calls, double* step_ms);
 
+/* ------------------------------------------------------------------------ RAR
+ * RAR generator (deps/rar/modeling/rar.py): adaLN blocks, per-head q/k LayerNorm, KV cache,
+ * classifier-free guidance.  Tensors by the checkpoint's key names (cls_token, embeddings.weight,
+ * pos_embed, target_aware_pos_embed, timesteps_embeddings, blocks.N.{norm1,norm2}.{weight,bias},
+ * blocks.N.attn.{qkv,proj}.{weight,bias}, blocks.N.attn.{q_norm,k_norm}.{weight,bias},
+ * blocks.N.mlp.{fc1,fc2}.{weight,bias}, blocks.N.adaLN_modulation.1.{weight,bias},
+ * adaln_before_head.adaLN_modulation.1.{weight,bias}, lm_head.{weight,bias}). */
+typedef struct wmar_rar_config {
+    int32_t hidden_size, num_hidden_layers, num_attention_heads, intermediate_size;
+    int32_t image_seq_len, codebook_size, condition_num_classes;
+    int32_t max_batch;   /* images per call; rows double under guidance */
+} wmar_rar_config;
+
+typedef struct wmar_rar wmar_rar;
+
+int wmar_rar_create(const wmar_rar_config* cfg, const char* const* names, const void* const* tensors_dev,
+                    int32_t n_tensors, void* stream, wmar_rar** out);
+void wmar_rar_destroy(wmar_rar* g);
+int64_t wmar_rar_device_bytes(const wmar_rar* g);
+
+/* RAR.forward_fn for ONE sequence position with a warm KV cache (rar.py:319-405): row m consumes
+ * tok_dev[m] (-1 = the cls token) at position `pos` under condition id cond_ids_dev[m] (already offset:
+ * class + codebook_size + 1, or the "none" id) and yields logits_dev float [M, codebook].  Positions in
+ * order 0,1,2,...  Used by the parity tests. */
+int wmar_rar_forward_position(wmar_rar* g, const int64_t* tok_dev, const int64_t* cond_ids_dev, int64_t M, int32_t pos,
+                              float* logits_dev, void* stream);
+
+/* RAR.generate (rar.py:408-459): class_ids_dev int64 [B] in [0, classes); cfg_scale_host float
+ * [image_seq_len] = the reference's per-step cfg_scale (host; ignored when use_guidance == 0);
+ * q_dev float [image_seq_len, B, V] Exp(1) noise; tokens_out_dev int64 [B, image_seq_len].
+ * The watermark context is the generated ids only, so the first token is never biased. */
+int wmar_rar_generate(wmar_rar* g, const wmar_wm_ctx* wm, const int64_t* class_ids_dev, int64_t B,
+                      const float* cfg_scale_host, int32_t use_guidance, float temperature, const float* q_dev,
+                      int64_t* tokens_out_dev, int32_t use_graph, void* stream);
+
 /* ---------------------------------------------------------------------- VQGAN
  * Taming VQGAN (deps/taming/models/vqgan.py:30-73, modules/diffusionmodules/model.py:343-538,
  * modules/vqvae/quantize.py:272-331).  Tensors by key name relative to `first_stage_model.`

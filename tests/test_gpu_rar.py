@@ -1,0 +1,100 @@
+"""HIP RAR engine (adaLN blocks, qk-norm, KV cache, guidance) against the oracle and the
+reference's golden logits/tokens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import rar_oracle as R  # noqa: E402
+from oracle import wm_oracle as W  # noqa: E402
+from tests.conftest import REPO  # noqa: E402
+from tests.test_gpu_watermark import _wm  # noqa: E402
+from wmar_amd.utils import synth  # noqa: E402
+
+RCFG = synth.RARConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
+                       image_seq_len=16, codebook_size=1024, condition_num_classes=1000)
+
+
+@pytest.fixture(scope="module")
+def rv():
+    return np.load(os.path.join(REPO, "tests", "golden", "rar_vectors.npz"))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from wmar_amd.models.engine import RAREngine
+    sd = synth.synth_rar_state(RCFG, seed=2, logit_scale=30.0)
+    return RAREngine(RCFG, sd, max_batch=8), sd
+
+
+def test_forward_positions_golden(rv, eng):
+    """teacher-forced positions: logits equal the reference's (cond rows then uncond rows)."""
+    e, _ = eng
+    toks = rv["rar_tokens_wm"]
+    B = toks.shape[0]
+    cond = torch.from_numpy(rv["rar_cond"]) + RCFG.codebook_size + 1
+    both = torch.cat([cond, torch.full_like(cond, RCFG.none_condition_id)]).cuda()
+    e.forward_position(torch.full((2 * B,), -1, dtype=torch.int64).cuda(), both, 0)
+    tok = both
+    for n in range(rv["rar_logits"].shape[0]):
+        lg = e.forward_position(tok, both, n + 1).cpu().numpy()
+        np.testing.assert_allclose(lg, rv["rar_logits"][n], rtol=0, atol=5e-4)
+        t = torch.from_numpy(toks[:, n])
+        tok = torch.cat([t, t]).cuda()
+
+
+@pytest.mark.parametrize("hd_cfg", [(160, 2, 640), (192, 4, 384)])   # head_dim 80 and 48 (padded row groups)
+def test_forward_odd_head_dims_vs_oracle(hd_cfg):
+    from wmar_amd.models.engine import RAREngine
+    d, H, F = hd_cfg
+    cfg = synth.RARConfig(hidden_size=d, num_hidden_layers=2, num_attention_heads=H, intermediate_size=F,
+                          image_seq_len=16, codebook_size=256, condition_num_classes=10)
+    sd = synth.synth_rar_state(cfg, seed=7, logit_scale=20.0)
+    e = RAREngine(cfg, sd, max_batch=4)
+    M = 6
+    rs = np.random.RandomState(0)
+    cond = torch.from_numpy(rs.randint(257, 267, size=M).astype(np.int64))
+    ce = sd["embeddings.weight"][cond]
+    cls = sd["cls_token"][0, 0].expand(M, -1)
+    _, kc, vc = R.rar_position(sd, cfg, cls, ce, 0, None, None)
+    e.forward_position(torch.full((M,), -1, dtype=torch.int64).cuda(), cond.cuda(), 0)
+    tok = cond
+    for p in range(1, 6):
+        ref, kc, vc = R.rar_position(sd, cfg, sd["embeddings.weight"][tok], ce, p, kc, vc)
+        lg = e.forward_position(tok.cuda(), cond.cuda(), p).cpu().numpy()
+        np.testing.assert_allclose(lg, ref.numpy(), rtol=0, atol=5e-4)
+        tok = torch.from_numpy(rs.randint(0, 256, size=M).astype(np.int64))
+
+
+@pytest.mark.parametrize("graph", [True, False])
+@pytest.mark.parametrize("tag,gs,gp,T,use_wm", [("wm", 4.0, 0.0, 1.0, True), ("nowm", 4.0, 0.0, 1.0, False),
+                                                ("pow", 3.0, 1.5, 0.9, True)])
+def test_generate_reproduces_reference_tokens(rv, kat, eng, tag, gs, gp, T, use_wm, graph):
+    e, _ = eng
+    wm = _wm(kat["keys"]["rar"])
+    torch.manual_seed(21)
+    torch.rand(4, 1)   # the label-drop mask draw of preprocess_condition precedes the sampling noise (rar.py:305)
+    q = torch.stack([torch.empty(4, 1024).exponential_(1) for _ in range(16)]).cuda()
+    toks = e.generate(torch.from_numpy(rv["rar_cond"]).cuda(), q, R.cfg_scales(16, gs, gp), T,
+                      wm.wm_ctx() if use_wm else None, use_graph=graph)
+    assert np.array_equal(toks.cpu().numpy(), rv[f"rar_tokens_{tag}"])
+
+
+def test_generate_without_guidance_vs_oracle(eng, kat, key_factory):
+    e, sd = eng
+    wm = _wm(kat["keys"]["rar"])
+    key = key_factory(kat["keys"]["rar"])
+    B = 5
+    g = torch.Generator().manual_seed(3)
+    q = torch.empty(16, B, 1024).exponential_(1, generator=g)
+    cond = torch.tensor([0, 999, 17, 400, 123])
+    ref = R.generate(sd, RCFG, cond, guidance_scale=0, key=key, delta=2.0, q_source=lambda n, b, v: q[n],
+                     draw_drop_mask=False)
+    toks = e.generate(cond.cuda(), q.cuda(), None, 1.0, wm.wm_ctx())
+    assert np.array_equal(toks.cpu().numpy(), ref.numpy())
+    pv = wm.detect(toks)
+    rpv, _, _ = W.detect(key, ref.numpy())
+    assert np.allclose(pv.cpu().numpy(), rpv, rtol=1e-9, atol=0, equal_nan=True)

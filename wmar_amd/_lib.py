@@ -17,7 +17,8 @@ SYMBOLS = [
     "wmar_last_error", "wmar_version", "wmar_key_row_words", "wmar_key_table_rows", "wmar_key_table_build",
     "wmar_key_greenlist", "wmar_wm_process_logits", "wmar_sample_fused", "wmar_detect", "wmar_detect_num_ngrams",
     "wmar_gpt_create", "wmar_gpt_destroy", "wmar_gpt_device_bytes", "wmar_gpt_decode_step", "wmar_gpt_generate",
-    "wmar_gpt_set_timing", "wmar_gpt_get_timing", "wmar_gpt_profile_role", "wmar_vq_create", "wmar_vq_destroy", "wmar_vq_device_bytes",
+    "wmar_gpt_set_timing", "wmar_gpt_get_timing", "wmar_gpt_profile_role", "wmar_rar_create", "wmar_rar_destroy",
+    "wmar_rar_device_bytes", "wmar_rar_forward_position", "wmar_rar_generate", "wmar_vq_create", "wmar_vq_destroy", "wmar_vq_device_bytes",
     "wmar_vq_decode", "wmar_vq_encode",
 ]
 
@@ -39,6 +40,12 @@ class WmCtx(C.Structure):
 class GptConfig(C.Structure):
     _fields_ = [("vocab_size", C.c_int32), ("block_size", C.c_int32), ("n_layer", C.c_int32),
                 ("n_head", C.c_int32), ("n_embd", C.c_int32), ("max_batch", C.c_int32)]
+
+
+class RarConfig(C.Structure):
+    _fields_ = [("hidden_size", C.c_int32), ("num_hidden_layers", C.c_int32), ("num_attention_heads", C.c_int32),
+                ("intermediate_size", C.c_int32), ("image_seq_len", C.c_int32), ("codebook_size", C.c_int32),
+                ("condition_num_classes", C.c_int32), ("max_batch", C.c_int32)]
 
 
 class SampleParams(C.Structure):
@@ -99,6 +106,13 @@ def load():
     L.wmar_gpt_set_timing.argtypes = [vp, i32]
     L.wmar_gpt_profile_role.argtypes = [vp, i32, i64, i32, i32, vp, C.POINTER(f64)]
     L.wmar_gpt_get_timing.argtypes = [vp, C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]
+    L.wmar_rar_create.argtypes = [C.POINTER(RarConfig), C.POINTER(C.c_char_p), C.POINTER(vp), i32, vp, C.POINTER(vp)]
+    L.wmar_rar_destroy.argtypes = [vp]
+    L.wmar_rar_destroy.restype = None
+    L.wmar_rar_device_bytes.restype = i64
+    L.wmar_rar_device_bytes.argtypes = [vp]
+    L.wmar_rar_forward_position.argtypes = [vp, vp, vp, i64, i32, vp, vp]
+    L.wmar_rar_generate.argtypes = [vp, C.POINTER(WmCtx), vp, i64, C.POINTER(f32), i32, f32, vp, vp, i32, vp]
     if hasattr(L, "wmar_vq_create"):
         L.wmar_vq_create.argtypes = [C.POINTER(VqConfig), C.POINTER(C.c_char_p), C.POINTER(vp), i32, vp, C.POINTER(vp)]
         L.wmar_vq_destroy.argtypes = [vp]

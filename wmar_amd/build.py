@@ -17,6 +17,7 @@ SOURCES = [
     ("keytable.cpp", []),
     ("watermark.hip", ["-ffp-contract=off"]),
     ("gpt.hip", []),
+    ("rar.hip", []),
     ("vqgan.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

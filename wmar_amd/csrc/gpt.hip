@@ -21,595 +21,8 @@
 #include <string>
 #include <vector>
 
-#include "sampler.h"
+#include "decoder_host.h"
 
-namespace wmar {
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-// streamed-once data (weights): non-temporal 16-byte load
-__device__ __forceinline__ float4 ld_nt(const float4* p) {
-    f32x4 v = __builtin_nontemporal_load((const f32x4*)p);
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-
-constexpr int MAX_SLABS = 8;
-constexpr int QKV_SLABS_MAX = 4;   // the QKV projection is split at most 4 ways (1 by default)
-constexpr int STAT_CHUNKS_MAX = 64;   // n_embd <= 8192
-constexpr int GEMM_STAGE = 4;   // k-blocks (of 8) per register stage of the skinny GEMM
-
-// ------------------------------------------------------------------------ weight packing
-// gamma (nullable): the LayerNorm scale of the layer that feeds this Linear, folded into
-// the weights ( LN(x) W^T = xhat (W*gamma)^T + W beta ), so the GEMM's inner loop only
-// has to form xhat = (x - mean) * rstd.
-__global__ void k_pack_linear(const float* __restrict__ W, float4* __restrict__ Wp, int N, int K, int nt_off,
-                              int KB, const float* __restrict__ gamma) {
-    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over (N/32)*KB*64
-    long long total = (long long)(N / 32) * KB * 64;
-    if (idx >= total) return;
-    int lane = (int)(idx & 63);
-    long long r = idx >> 6;
-    int kb = (int)(r % KB);
-    int nt = (int)(r / KB);
-    int n = nt * 32 + (lane & 31);
-    int k = kb * 8 + 4 * (lane >> 5);
-    const float* src = W + (long long)n * K + k;
-    float4 v = make_float4(src[0], src[1], src[2], src[3]);
-    if (gamma) { v.x *= gamma[k]; v.y *= gamma[k + 1]; v.z *= gamma[k + 2]; v.w *= gamma[k + 3]; }
-    Wp[((long long)(nt + nt_off) * KB + kb) * 64 + lane] = v;
-}
-
-// out[n] = (bias ? bias[n] : 0) + sum_k W[n][k] * v[k]   (one wave per output row; v = LN beta or gamma)
-__global__ __launch_bounds__(64) void k_fold_bias(const float* __restrict__ W, const float* __restrict__ bias,
-                                                  const float* __restrict__ beta, float* __restrict__ out, int K) {
-    const int n = blockIdx.x, lane = threadIdx.x;
-    double acc = 0.0;
-    for (int k = lane; k < K; k += 64) acc += (double)W[(long long)n * K + k] * (double)beta[k];
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) out[n] = (float)((bias ? (double)bias[n] : 0.0) + acc);
-}
-
-__global__ void k_set_int(int* p, int v) { *p = v; }
-__global__ void k_advance3(int* p) { p[0] += 1; p[1] += 1; p[2] += 1; }  // pos, step, len
-
-// --------------------------------------------------- residual update + LayerNorm statistics
-// x_new = EMBED ? tok_emb[tok[m]] + pos_emb[pos]
-//               : x + bias + sum_s slab[s]          (fixed summation order)
-// and per (chunk, row) partial sums (sum, sum of squares) in fp64 for the consumer's fused LN.
-struct ResidArgs {
-    float4* x;                 // packed [KB][MT][64]
-    const float4* slabs;       // [S][KB*MT*64]
-    long long slab_stride;     // float4 units
-    int S;
-    const float* bias;         // [K]
-    double* stats;             // [n_chunks][Mpad][2]
-    int KB, MT, n_chunks;
-    // embed
-    const float* tok_emb;      // [V][K]
-    const float* pos_emb;      // [block][K]
-    const long long* tok;      // token of row m: tok[m*tok_stride + (tok_use_pos ? *pos : 0)]
-    long long tok_stride;
-    int tok_use_pos;
-    const int* pos_dev;
-    int B, K;
-};
-
-// S = number of partial slabs (compile-time so that every load of a wave is issued up front:
-// the kernel is a handful of dependent L2 round trips, not bandwidth).
-template <bool EMBED, int S>
-__global__ __launch_bounds__(256) void k_resid_stats(ResidArgs a) {
-    constexpr int KPW = 4;  // k-blocks per wave (host guarantees chunk length <= 4*KPW)
-    __shared__ double red[4][32][2];
-    const int c = blockIdx.x / a.MT, mt = blockIdx.x % a.MT;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int kb0 = (int)((long long)c * a.KB / a.n_chunks), kb1 = (int)((long long)(c + 1) * a.KB / a.n_chunks);
-    const int m = mt * 32 + (lane & 31), half = lane >> 5;
-    const float* erow = nullptr;
-    const float* prow = nullptr;
-    if (EMBED) {
-        int pos = *a.pos_dev;
-        long long tk = (m < a.B) ? a.tok[(long long)m * a.tok_stride + (a.tok_use_pos ? pos : 0)] : 0;
-        erow = a.tok_emb + tk * a.K;
-        prow = a.pos_emb + (long long)pos * a.K;
-    }
-    float4 v[KPW], bb[KPW], sl[KPW][S > 0 ? S : 1];
-    int kbs[KPW];
-#pragma unroll
-    for (int i = 0; i < KPW; ++i) {
-        const int kb = kb0 + w + 4 * i;
-        kbs[i] = kb < kb1 ? kb : -1;
-        const int kk = kb < kb1 ? kb : kb0;  // in-bounds dummy for idle slots
-        const long long idx = ((long long)kk * a.MT + mt) * 64 + lane;
-        const int k = kk * 8 + 4 * half;
-        if (EMBED) {
-            v[i] = *(const float4*)(erow + k);
-            bb[i] = *(const float4*)(prow + k);
-        } else {
-            v[i] = a.x[idx];
-            bb[i] = *(const float4*)(a.bias + k);
-#pragma unroll
-            for (int sidx = 0; sidx < S; ++sidx) sl[i][sidx] = a.slabs[(long long)sidx * a.slab_stride + idx];
-        }
-    }
-    double s = 0.0, ss = 0.0;
-#pragma unroll
-    for (int i = 0; i < KPW; ++i) {
-        if (kbs[i] < 0) continue;
-        float4 r;
-        if (EMBED) {
-            r = make_float4(v[i].x + bb[i].x, v[i].y + bb[i].y, v[i].z + bb[i].z, v[i].w + bb[i].w);
-        } else {
-            float4 acc = sl[i][0];
-#pragma unroll
-            for (int sidx = 1; sidx < S; ++sidx) {
-                acc.x += sl[i][sidx].x; acc.y += sl[i][sidx].y; acc.z += sl[i][sidx].z; acc.w += sl[i][sidx].w;
-            }
-            r = make_float4(v[i].x + (bb[i].x + acc.x), v[i].y + (bb[i].y + acc.y), v[i].z + (bb[i].z + acc.z),
-                            v[i].w + (bb[i].w + acc.w));
-        }
-        a.x[((long long)kbs[i] * a.MT + mt) * 64 + lane] = r;
-        s += (double)r.x + (double)r.y + (double)r.z + (double)r.w;
-        ss += (double)r.x * r.x + (double)r.y * r.y + (double)r.z * r.z + (double)r.w * r.w;
-    }
-    s += __shfl_xor(s, 32);
-    ss += __shfl_xor(ss, 32);
-    if (lane < 32) { red[w][lane][0] = s; red[w][lane][1] = ss; }
-    __syncthreads();
-    if (threadIdx.x < 32) {
-        double ts = 0, tss = 0;
-        for (int i = 0; i < 4; ++i) { ts += red[i][threadIdx.x][0]; tss += red[i][threadIdx.x][1]; }
-        const int Mpad = a.MT * 32;
-        double* o = a.stats + ((long long)c * Mpad + mt * 32 + threadIdx.x) * 2;
-        o[0] = ts; o[1] = tss;
-    }
-}
-
-template <int S>
-static void launch_resid_s(const ResidArgs& r, int grid, hipStream_t st) {
-    hipLaunchKernelGGL((k_resid_stats<false, S>), dim3(grid), dim3(256), 0, st, r);
-}
-static int launch_resid(const ResidArgs& r, int grid, hipStream_t st) {
-    switch (r.S) {
-        case 1: launch_resid_s<1>(r, grid, st); break;
-        case 2: launch_resid_s<2>(r, grid, st); break;
-        case 3: launch_resid_s<3>(r, grid, st); break;
-        case 4: launch_resid_s<4>(r, grid, st); break;
-        case 5: launch_resid_s<5>(r, grid, st); break;
-        case 6: launch_resid_s<6>(r, grid, st); break;
-        case 7: launch_resid_s<7>(r, grid, st); break;
-        case 8: launch_resid_s<8>(r, grid, st); break;
-        default: set_error("resid: bad slab count %d", r.S); return WMAR_EINVAL;
-    }
-    return launch_status("k_resid_stats");
-}
-
-// mean / rstd of row m from the per-chunk fp64 partial sums written by k_resid_stats.
-// All loads of a group of 16 chunks are issued together (one L2 round trip, not one per chunk).
-__device__ __forceinline__ void ln_row_stats(const double* __restrict__ stats, int n_chunks, int Mpad, int m, int K,
-                                             float* mu, float* rstd) {
-    double sm = 0, sq = 0;
-    for (int c0 = 0; c0 < n_chunks; c0 += 16) {
-        double2 v[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int c = min(c0 + i, n_chunks - 1);
-            v[i] = *(const double2*)(stats + ((long long)c * Mpad + m) * 2);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (c0 + i < n_chunks) { sm += v[i].x; sq += v[i].y; }
-    }
-    const double invK = 1.0 / (double)K;
-    const double mean = sm * invK;
-    *mu = (float)mean;
-    *rstd = rsqrtf((float)(sq * invK - mean * mean) + 1e-5f);
-}
-
-// ------------------------------------------------------------------------- skinny GEMM
-enum { EPI_PACKED = 0, EPI_GELU = 1, EPI_QKV = 2, EPI_LOGITS = 3 };
-
-struct GemmArgs {
-    const float4* Wp;          // [NT][KB][64]
-    const float4* Xp;          // [KB][MT][64]
-    const float* bias;         // [N] or null
-    const float* c1;           // [N] row sums of the gamma-folded weights (LN epilogue), or null
-    int KB, NT, MT, S;
-    // fused LayerNorm on the B operand
-    const double* stats; int n_chunks; int K;
-    // epilogues
-    float4* out_packed; long long slab_stride;          // EPI_PACKED (slab s) / EPI_GELU
-    float* qbuf; float* kcache; float* vcache;          // EPI_QKV
-    const int* pos_dev; int D, H, hd, Tmax;
-    float* logits; int V;                               // EPI_LOGITS
-    int B;
-    unsigned long long* trace;                          // dev only (WMAR_GEMM_TRACE): 4 timestamps per workgroup
-};
-
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-
-// grid = NT * (MT/MTW) * S workgroups of NW waves.  Each workgroup owns one 32-column
-// tile of the output for MTW row tiles and one K slice; its NW waves split that K slice
-// and reduce through LDS in a fixed order.
-template <int MTW, int NW, int EPI, bool LN, int ABL = 0, int U = GEMM_STAGE, bool ROT = true>
-__global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [NW][MTW*16][64]
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int MG = a.MT / MTW;
-    int bid = blockIdx.x;
-    const int nt = bid % a.NT; bid /= a.NT;
-    const int mg = bid % MG;
-    const int s = bid / MG;
-    const int mt0 = mg * MTW;
-    const int slices = a.S * NW;
-    const int sl = s * NW + w;
-    // 32-bit index math (there is no integer divide instruction: 64-bit division is ~10x dearer)
-    const int kb0 = (int)((unsigned)sl * (unsigned)a.KB / (unsigned)slices);
-    const int kb1 = (int)((unsigned)(sl + 1) * (unsigned)a.KB / (unsigned)slices);
-    const int half = lane >> 5;
-#ifdef WMAR_GEMM_TRACE
-    unsigned long long tr0 = __builtin_amdgcn_s_memtime(), tr1 = 0, tr2 = 0;
-#endif
-
-    f32x16 acc[MTW];
-#pragma unroll
-    for (int i = 0; i < MTW; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-    float mu[MTW], rstd[MTW];
-    const float4* Wp = a.Wp + (long long)nt * a.KB * 64 + lane;
-    const float4* Xp = a.Xp + (long long)mt0 * 64 + lane;
-    const long long xstep = (long long)a.MT * 64;
-
-    // Register double buffer: while the MFMAs of one stage (U k-blocks = 4U instructions per
-    // row tile) run, the loads of the next stage are in flight.
-    float4 wA[U], wB[U], xA[U][MTW], xB[U][MTW];
-#define WMAR_LOAD(WBUF, XBUF, KB0)                                                              \
-    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                            \
-        const int kk = (KB0) + u;                                                               \
-        WBUF[u] = (ABL == 2) ? make_float4(1.f, 2.f, 3.f, (float)kk) : ld_nt(Wp + (long long)kk * 64); \
-        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
-            XBUF[u][i] = (ABL == 1) ? make_float4(1.f, 2.f, 3.f, (float)kk) : Xp[(long long)kk * xstep + i * 64]; \
-    }
-#define WMAR_LN_PROLOGUE                                                                        \
-    if (LN) {                                                                                   \
-        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
-            ln_row_stats(a.stats, a.n_chunks, a.MT * 32, (mt0 + i) * 32 + (lane & 31), a.K, &mu[i], &rstd[i]); \
-    }
-#define WMAR_LNX(XV)
-#define WMAR_MMA1(WV, XV)                                                                       \
-    {                                                                                           \
-        if (ABL == 3) {                                                                         \
-            _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                    \
-                acc[i][0] += WV.x * XV[i].x + WV.y * XV[i].y + WV.z * XV[i].z + WV.w * XV[i].w; \
-        } else {                                                                                \
-        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV.x, XV[i].x, acc[i], 0, 0, 0);      \
-        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV.y, XV[i].y, acc[i], 0, 0, 0);      \
-        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV.z, XV[i].z, acc[i], 0, 0, 0);      \
-        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV.w, XV[i].w, acc[i], 0, 0, 0);      \
-        }                                                                                       \
-    }
-// the normalisation of k-block u+1 is issued ahead of the MFMAs of k-block u (VALU under MFMA),
-// and each k-block only waits for its own loads
-#define WMAR_MMA(WBUF, XBUF)                                                                    \
-    WMAR_LNX(XBUF[0])                                                                           \
-    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                            \
-        if (u + 1 < U) { WMAR_LNX(XBUF[u + 1]) }                                                \
-        WMAR_MMA1(WBUF[u], XBUF[u])                                                             \
-    }
-    int kb = kb0;
-    const int nfull = (kb1 - kb0) / (2 * U);
-    if (nfull > 0) {
-        // Every workgroup of a launch walks the SAME activation rows.  Started in lockstep they
-        // would all hit the same few L2 channels at once (measured: 4.7 TB/s aggregate instead of
-        // >30), so each output tile starts its K walk at a different stage and wraps around.
-        // The summation order per tile stays fixed (it depends on the tile index only).
-        const int nst = 2 * nfull;
-        const int rot = (ROT ? (nt * 5 + mg * 3) : 0) % nst;
-#define WMAR_STAGE_KB(SI) (kb0 + (((SI) + rot) % nst) * U)
-        // sched_barrier(0): hipcc otherwise sinks every load down to its first use (it minimises
-        // registers), which serialises load -> wait -> 4 MFMAs.
-        WMAR_LOAD(wA, xA, WMAR_STAGE_KB(0))
-        __builtin_amdgcn_sched_barrier(0);
-        // LayerNorm statistics are fetched AFTER the first operand loads are in flight
-        WMAR_LN_PROLOGUE
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef WMAR_GEMM_TRACE
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        tr1 = __builtin_amdgcn_s_memtime();
-#endif
-        for (int it = 0; it < nfull; ++it) {
-            WMAR_LOAD(wB, xB, WMAR_STAGE_KB(2 * it + 1))
-            __builtin_amdgcn_sched_barrier(0);
-            WMAR_MMA(wA, xA)
-            __builtin_amdgcn_sched_barrier(0);
-            // last round: re-read an in-bounds stage instead of branching around the loads
-            WMAR_LOAD(wA, xA, WMAR_STAGE_KB((2 * it + 2) % nst))
-            __builtin_amdgcn_sched_barrier(0);
-            WMAR_MMA(wB, xB)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#undef WMAR_STAGE_KB
-        kb = kb0 + nst * U;
-    } else {
-        WMAR_LN_PROLOGUE
-    }
-    for (; kb < kb1; ++kb) {  // tail (slices that are not a multiple of 2U blocks)
-        float4 wv = ld_nt(Wp + (long long)kb * 64);
-        float4 xt[MTW];
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) xt[i] = Xp[(long long)kb * xstep + i * 64];
-        WMAR_LNX(xt)
-        WMAR_MMA1(wv, xt)
-    }
-#undef WMAR_MMA1
-#undef WMAR_LNX
-#undef WMAR_LN_PROLOGUE
-#undef WMAR_LOAD
-#undef WMAR_MMA
-
-#ifdef WMAR_GEMM_TRACE
-    tr2 = __builtin_amdgcn_s_memtime();
-#endif
-    // in-workgroup K reduction (fixed order) + epilogue
-    float* my = smem + (long long)w * (MTW * 16) * 64;
-#pragma unroll
-    for (int i = 0; i < MTW; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) my[(i * 16 + r) * 64 + lane] = acc[i][r];
-    __syncthreads();
-
-    for (int grp = w; grp < MTW * 4; grp += NW) {
-        const int i = grp >> 2, g = grp & 3;
-        float o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float t = 0.f;
-            for (int ww = 0; ww < NW; ++ww) t += smem[((long long)ww * (MTW * 16) + i * 16 + g * 4 + j) * 64 + lane];
-            o[j] = t;
-        }
-        const int mt = mt0 + i;
-        const int n = nt * 32 + g * 8 + half * 4;       // first of 4 consecutive output columns
-        const int m = mt * 32 + (lane & 31);
-        if (LN) {
-            // LN(x) W^T = rstd * (x W'^T - mean * rowsum(W')) + (bias + W beta):  the main loop ran on raw x
-            const float4 cc = *(const float4*)(a.c1 + n);
-            const float mm = mu[i], rs = rstd[i];
-            o[0] = rs * (o[0] - mm * cc.x); o[1] = rs * (o[1] - mm * cc.y);
-            o[2] = rs * (o[2] - mm * cc.z); o[3] = rs * (o[3] - mm * cc.w);
-        }
-        if (a.bias) {
-            float4 bb = *(const float4*)(a.bias + n);
-            o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w;
-        }
-        if (EPI == EPI_PACKED || EPI == EPI_GELU) {
-            if (EPI == EPI_GELU) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = gelu_erf(o[j]);
-            }
-            // output column n is input feature k' = n of the next GEMM: kb' = n/8
-            float4* dst = a.out_packed + (long long)s * a.slab_stride + ((long long)(nt * 4 + g) * a.MT + mt) * 64 + lane;
-            *dst = make_float4(o[0], o[1], o[2], o[3]);
-        } else if (EPI == EPI_QKV) {
-            if (m < a.B) {
-                const int which = n / a.D, c = n % a.D;
-                if (which == 0) {
-                    *(float4*)(a.qbuf + (long long)m * a.D + c) = make_float4(o[0], o[1], o[2], o[3]);
-                } else {
-                    const int hh = c / a.hd, d = c % a.hd;
-                    const int pos = *a.pos_dev;
-                    float* base = (which == 1) ? a.kcache : a.vcache;
-                    *(float4*)(base + (((long long)m * a.H + hh) * a.Tmax + pos) * a.hd + d) = make_float4(o[0], o[1], o[2], o[3]);
-                }
-            }
-        } else {  // EPI_LOGITS
-            if (m < a.B) *(float4*)(a.logits + (long long)m * a.V + n) = make_float4(o[0], o[1], o[2], o[3]);
-        }
-    }
-#ifdef WMAR_GEMM_TRACE
-    if (a.trace && threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long* t = a.trace + (long long)blockIdx.x * 4;
-        t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = __builtin_amdgcn_s_memtime();
-    }
-#endif
-}
-
-// --------------------------------------------------------------------- decode attention
-// One wave per (sequence, head).  K/V rows are hd floats; LPR = hd/4 lanes cover a row with
-// float4s and RPI = 64/LPR rows are read per wave-wide load (1 KiB, coalesced).
-struct AttnArgs {
-    // The QKV projection arrives as S split-K partial slabs in packed layout (columns
-    // [q | k | v], 3*D wide).  The attention wave of (sequence, head) finishes its own
-    // 3 x hd columns -- LayerNorm algebra, bias -- appends k and v to the cache and goes on.
-    const float4* qkv_slabs;   // [S][(3D/8)][MT][64]
-    long long slab_stride;     // float4 units
-    int S;
-    const double* stats; int n_chunks; int K;   // LN1 row statistics (see k_resid_stats)
-    const float* c1;           // [3D] row sums of the gamma-folded QKV weights
-    const float* bias;         // [3D] bias + W beta
-    float* kcache;             // [B][H][Tmax][hd] (this layer)
-    float* vcache;
-    float4* y;                 // packed [KB][MT][64]
-    const int* pos_dev;
-    int D, H, Tmax, MT;
-    float scale;
-    int dbg;                   // dev ablation (WMAR_ATT_DBG): 2 = skip K/V streaming
-};
-
-// One workgroup of NWA waves per (sequence, head).  The cached rows are cut into chunks of
-// CH 1-KiB loads (CH*RPI rows); wave w takes chunks w, w+NWA, ...  and keeps a running
-// (max, sum, weighted V sum) in registers -- K and V of a chunk are requested together, the next
-// chunk is in flight while the current one is reduced.  The NWA partial results meet in LDS.
-template <int HD, int NWA>
-__global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
-    constexpr int LPR = HD / 4, RPI = 64 / LPR;
-    constexpr int CH = 8;
-    constexpr int ROWS = CH * RPI;
-    __shared__ float part[NWA][HD + 2];    // per wave: weighted V sum [HD], max, sum
-    __shared__ __attribute__((aligned(16))) float qkv_s[3][HD];
-    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int T = *a.pos_dev + 1;
-    const int sub = lane % LPR, rsel = lane / LPR;
-    float* Kc = a.kcache + ((long long)b * a.H + h) * a.Tmax * HD + sub * 4;
-    float* Vc = a.vcache + ((long long)b * a.H + h) * a.Tmax * HD + sub * 4;
-    const int nchunk = (a.dbg & 2) ? 0 : (T + ROWS - 1) / ROWS;
-
-    // rows past T-1 are clamped to T-1 and replaced from registers / masked below
-#define WMAR_ATT_LOAD(KB, VB, C0)                                                        \
-    _Pragma("unroll") for (int u = 0; u < CH; ++u) {                                     \
-        const int t = min((C0) * ROWS + u * RPI + rsel, T - 1);                          \
-        KB[u] = *(const float4*)(Kc + (long long)t * HD);                                \
-        VB[u] = *(const float4*)(Vc + (long long)t * HD);                                \
-    }
-    float4 kA[CH], vA[CH], kB[CH], vB[CH];
-    float4 q, knew, vnew;
-    if (w < nchunk) { WMAR_ATT_LOAD(kA, vA, w) }   // in flight while q/k/v are finished
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- wave 0 finishes this head's q, k, v for the new token from the QKV slab(s) and hands
-    // them to the other waves through LDS.  Loads are issued by as few lanes as possible: a
-    // wave-wide load of one shared address still costs the address path a full 64-lane pass.
-    if (w == 0) {
-        // every load of the prologue is issued before the first wait: LN partial sums (one chunk per
-        // lane), the QKV slab(s), the folded-LN row sums and the bias (16 lanes each)
-        const int Mpad = a.MT * 32;
-        const int mt = b >> 5;
-        double sm = 0, sq = 0;
-        double2 st0 = make_double2(0.0, 0.0);
-        if (lane < a.n_chunks) st0 = *(const double2*)(a.stats + ((long long)lane * Mpad + b) * 2);
-        float4 sl[3][QKV_SLABS_MAX], cc[3], bb[3];
-        if (rsel == 0) {
-#pragma unroll
-            for (int which = 0; which < 3; ++which) {
-                const int n = which * a.D + h * HD + sub * 4;          // first of this lane's 4 columns
-                const long long idx = ((long long)(n >> 3) * a.MT + mt) * 64 + (b & 31) + 32 * ((n >> 2) & 1);
-#pragma unroll
-                for (int sidx = 0; sidx < QKV_SLABS_MAX; ++sidx)
-                    sl[which][sidx] = a.qkv_slabs[(long long)min(sidx, a.S - 1) * a.slab_stride + idx];
-                cc[which] = *(const float4*)(a.c1 + n);
-                bb[which] = *(const float4*)(a.bias + n);
-            }
-        }
-        sm = st0.x; sq = st0.y;
-        for (int c = lane + 64; c < a.n_chunks; c += 64) {     // n_embd > 8192 only
-            const double2 v = *(const double2*)(a.stats + ((long long)c * Mpad + b) * 2);
-            sm += v.x; sq += v.y;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
-        const double invK = 1.0 / (double)a.K;
-        const double mean = sm * invK;
-        const float mu = (float)mean;
-        const float rstd = rsqrtf((float)(sq * invK - mean * mean) + 1e-5f);
-        if (rsel == 0) {
-            float4 r[3];
-#pragma unroll
-            for (int which = 0; which < 3; ++which) {
-                float4 acc = sl[which][0];
-#pragma unroll
-                for (int sidx = 1; sidx < QKV_SLABS_MAX; ++sidx)
-                    if (sidx < a.S) {
-                        acc.x += sl[which][sidx].x; acc.y += sl[which][sidx].y;
-                        acc.z += sl[which][sidx].z; acc.w += sl[which][sidx].w;
-                    }
-                r[which] = make_float4(rstd * (acc.x - mu * cc[which].x) + bb[which].x,
-                                       rstd * (acc.y - mu * cc[which].y) + bb[which].y,
-                                       rstd * (acc.z - mu * cc[which].z) + bb[which].z,
-                                       rstd * (acc.w - mu * cc[which].w) + bb[which].w);
-                *(float4*)(&qkv_s[which][sub * 4]) = r[which];
-            }
-            // present = (k, v) of this step -> cache row T-1 (mingpt.py:77)
-            *(float4*)(Kc + (long long)(T - 1) * HD) = r[1];
-            *(float4*)(Vc + (long long)(T - 1) * HD) = r[2];
-        }
-    }
-    __syncthreads();
-    q = *(const float4*)(&qkv_s[0][sub * 4]);
-    knew = *(const float4*)(&qkv_s[1][sub * 4]);
-    vnew = *(const float4*)(&qkv_s[2][sub * 4]);
-    __builtin_amdgcn_sched_barrier(0);
-
-    float m = -INFINITY, l = 0.f;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#define WMAR_ATT_CHUNK(KB, VB, C0)                                                       \
-    {                                                                                    \
-        float sc[CH];                                                                    \
-        float cm = -INFINITY;                                                            \
-        _Pragma("unroll") for (int u = 0; u < CH; ++u) {                                 \
-            const int t = (C0) * ROWS + u * RPI + rsel;                                  \
-            if (t >= T - 1) { KB[u] = knew; VB[u] = vnew; }                              \
-            float p = KB[u].x * q.x + KB[u].y * q.y + KB[u].z * q.z + KB[u].w * q.w;     \
-            _Pragma("unroll") for (int o = 1; o < LPR; o <<= 1) p += __shfl_xor(p, o);   \
-            p = (t < T) ? p * a.scale : -INFINITY;                                       \
-            sc[u] = p;                                                                   \
-            cm = fmaxf(cm, p);                                                           \
-        }                                                                                \
-        _Pragma("unroll") for (int o = LPR; o < 64; o <<= 1) cm = fmaxf(cm, __shfl_xor(cm, o)); \
-        const float mn = fmaxf(m, cm);                                                   \
-        const float rs = __expf(m - mn);       /* 0 on the first chunk (m = -inf) */     \
-        l *= rs; acc.x *= rs; acc.y *= rs; acc.z *= rs; acc.w *= rs;                     \
-        _Pragma("unroll") for (int u = 0; u < CH; ++u) {                                 \
-            const float e = __expf(sc[u] - mn);                                          \
-            l += e;                                                                      \
-            acc.x += e * VB[u].x; acc.y += e * VB[u].y; acc.z += e * VB[u].z; acc.w += e * VB[u].w; \
-        }                                                                                \
-        m = mn;                                                                          \
-    }
-    for (int c = w; c < nchunk; c += 2 * NWA) {
-        if (c + NWA < nchunk) { WMAR_ATT_LOAD(kB, vB, c + NWA) }
-        __builtin_amdgcn_sched_barrier(0);
-        WMAR_ATT_CHUNK(kA, vA, c)
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 2 * NWA < nchunk) { WMAR_ATT_LOAD(kA, vA, c + 2 * NWA) }
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + NWA < nchunk) { WMAR_ATT_CHUNK(kB, vB, c + NWA) }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#undef WMAR_ATT_LOAD
-#undef WMAR_ATT_CHUNK
-    // fold the RPI row groups of this wave (l and acc are per-lane partials over the lane's rows)
-#pragma unroll
-    for (int o = LPR; o < 64; o <<= 1) {
-        l += __shfl_xor(l, o);
-        acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o);
-        acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
-    }
-    if (rsel == 0) {
-        *(float4*)(&part[w][sub * 4]) = acc;
-        if (sub == 0) { part[w][HD] = m; part[w][HD + 1] = l; }
-    }
-    __syncthreads();
-    if (w == 0 && rsel == 0) {
-        float M = part[0][HD];
-#pragma unroll
-        for (int i = 1; i < NWA; ++i) M = fmaxf(M, part[i][HD]);
-        float L = 0.f;
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int i = 0; i < NWA; ++i) {
-            const float f = __expf(part[i][HD] - M);   // waves without rows: exp(-inf) = 0
-            const float4 pa = *(const float4*)(&part[i][sub * 4]);
-            L += part[i][HD + 1] * f;
-            o.x += pa.x * f; o.y += pa.y * f; o.z += pa.z * f; o.w += pa.w * f;
-        }
-        const float inv = 1.0f / L;
-        // y[b][h*HD + sub*4 .. +3] into the packed activation layout
-        const int k = h * HD + sub * 4;
-        const int kb = k >> 3, hf = (k >> 2) & 1;
-        const int mt = b >> 5;
-        a.y[((long long)kb * a.MT + mt) * 64 + (b & 31) + 32 * hf] = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
-    }
-}
-
-}  // namespace wmar
 
 using namespace wmar;
 
@@ -711,88 +124,6 @@ struct wmar_gpt {
 };
 
 namespace {
-
-int mt_for(int64_t B) { return B <= 32 ? 1 : (B <= 64 ? 2 : 4); }
-
-struct TensorMap {
-    std::map<std::string, const void*> m;
-    const float* get(const std::string& k) const {
-        auto it = m.find(k);
-        return it == m.end() ? nullptr : (const float*)it->second;
-    }
-};
-
-int pack(wmar_gpt* g, const float* W, float4* Wp, int N, int K, int nt_off, hipStream_t st,
-         const float* gamma = nullptr) {
-    long long total = (long long)(N / 32) * (K / 8) * 64;
-    hipLaunchKernelGGL(k_pack_linear, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, Wp, N, K, nt_off, K / 8,
-                       gamma);
-    return launch_status("k_pack_linear");
-}
-
-// dst[0..N) = bias + W beta
-int fold_bias(const float* W, const float* bias, const float* beta, float* dst, int N, int K, hipStream_t st) {
-    hipLaunchKernelGGL(k_fold_bias, dim3((unsigned)N), dim3(64), 0, st, W, bias, beta, dst, K);
-    return launch_status("k_fold_bias");
-}
-
-int copy_vec(wmar_gpt* g, float** dst, const float* src, size_t n, hipStream_t st) {
-    if (int rc = g->alloc(dst, n)) return rc;
-    WMAR_HIP_CHECK(hipMemcpyAsync(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-    return WMAR_OK;
-}
-
-template <int MTW, int NW, int EPI, bool LN, int ABL = 0, int U = GEMM_STAGE, bool ROT = true>
-int launch_gemm(const GemmArgs& a, hipStream_t st) {
-    const int grid = a.NT * (a.MT / MTW) * a.S;
-    const size_t lds = (size_t)NW * MTW * 16 * 64 * sizeof(float);
-    hipLaunchKernelGGL((k_gemm<MTW, NW, EPI, LN, ABL, U, ROT>), dim3((unsigned)grid), dim3(NW * 64), lds, st, a);
-    return launch_status("k_gemm");
-}
-
-// Split-K factor for a GEMM whose partial slabs are folded by a later kernel: pick the S that
-// fills the 256 CUs most evenly (whole "rounds" of workgroups), keeping >= 8 k-blocks per wave.
-int pick_split(int tiles, int KB, int NW) {
-    int best = 1;
-    double best_eff = 0.0;
-    for (int S = 1; S <= MAX_SLABS; ++S) {
-        if (KB / (S * NW) < 8 && S > 1) break;
-        const int wgs = tiles * S;
-        const int rounds = (wgs + 255) / 256;
-        const double eff = (double)wgs / (rounds * 256.0);
-        if (eff > best_eff + 0.02) { best_eff = eff; best = S; }
-    }
-    return best;
-}
-
-// Row tiles per workgroup: two 32-row tiles share every weight fragment (half the operand
-// traffic per MFMA); a single tile when the batch has only one.
-template <int EPI, bool LN>
-int gemm_dispatch(GemmArgs a, bool allow_split, hipStream_t st) {
-    constexpr int NW = 4;
-    if (a.MT % 2 == 0) {
-        a.S = allow_split ? pick_split(a.NT * (a.MT / 2), a.KB, NW) : 1;
-        return launch_gemm<2, NW, EPI, LN>(a, st);
-    }
-    a.S = allow_split ? pick_split(a.NT * a.MT, a.KB, NW) : 1;
-    return launch_gemm<1, NW, EPI, LN>(a, st);
-}
-
-// split-K GEMM writing partial slabs; reports the S it used
-int gemm_split(GemmArgs a, int* S_out, hipStream_t st, int force_S = 0) {
-    constexpr int NW = 4;
-    if (a.MT % 2 == 0) {
-        a.S = force_S > 0 ? force_S : pick_split(a.NT * (a.MT / 2), a.KB, NW);
-        *S_out = a.S;
-        return launch_gemm<2, NW, EPI_PACKED, false>(a, st);
-    }
-    a.S = force_S > 0 ? force_S : pick_split(a.NT * a.MT, a.KB, NW);
-    *S_out = a.S;
-    return launch_gemm<1, NW, EPI_PACKED, false>(a, st);
-}
-
-// chunks of <= 16 k-blocks: one k_resid_stats workgroup (4 waves x 4 blocks) per chunk and row tile
-int stat_chunks(int KB) { return (KB + 15) / 16; }
 
 struct StepIO {
     const long long* tok;  // row m's token: tok[m*stride + (use_pos ? pos : 0)]
@@ -987,7 +318,7 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
         TRY(copy_vec(g, &g->tok_emb, te, (size_t)V * D, st));
         TRY(copy_vec(g, &g->pos_emb, pe, (size_t)cfg->block_size * D, st));
         TRY(g->alloc(&g->whead, (size_t)V * D / 4));
-        TRY(pack(g, hw, g->whead, V, D, 0, st, lfw));
+        TRY(pack(hw, g->whead, V, D, 0, st, lfw));
         TRY(g->alloc(&g->bhead, (size_t)V));
         TRY(fold_bias(hw, nullptr, lfb, g->bhead, V, D, st));
         TRY(g->alloc(&g->chead, (size_t)V));
@@ -1005,9 +336,9 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
         const float *l1w = need(p + "ln1.weight"), *l1b = need(p + "ln1.bias"), *l2w = need(p + "ln2.weight"), *l2b = need(p + "ln2.bias");
         if (rc != WMAR_OK) break;
         TRY(g->alloc(&w.wqkv, (size_t)3 * D * D / 4));
-        TRY(pack(g, qw, w.wqkv, D, D, 0, st, l1w));
-        TRY(pack(g, kw, w.wqkv, D, D, D / 32, st, l1w));
-        TRY(pack(g, vw, w.wqkv, D, D, 2 * D / 32, st, l1w));
+        TRY(pack(qw, w.wqkv, D, D, 0, st, l1w));
+        TRY(pack(kw, w.wqkv, D, D, D / 32, st, l1w));
+        TRY(pack(vw, w.wqkv, D, D, 2 * D / 32, st, l1w));
         TRY(g->alloc(&w.bqkv, (size_t)3 * D));
         TRY(fold_bias(qw, qb, l1b, w.bqkv, D, D, st));
         TRY(fold_bias(kw, kb, l1b, w.bqkv + D, D, D, st));
@@ -1017,16 +348,16 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
         TRY(fold_bias(kw, nullptr, l1w, w.cqkv + D, D, D, st));
         TRY(fold_bias(vw, nullptr, l1w, w.cqkv + 2 * D, D, D, st));
         TRY(g->alloc(&w.wproj, (size_t)D * D / 4));
-        TRY(pack(g, pw, w.wproj, D, D, 0, st));
+        TRY(pack(pw, w.wproj, D, D, 0, st));
         TRY(copy_vec(g, &w.bproj, pb, D, st));
         TRY(g->alloc(&w.wfc1, (size_t)4 * D * D / 4));
-        TRY(pack(g, f1w, w.wfc1, 4 * D, D, 0, st, l2w));
+        TRY(pack(f1w, w.wfc1, 4 * D, D, 0, st, l2w));
         TRY(g->alloc(&w.bfc1, (size_t)4 * D));
         TRY(fold_bias(f1w, f1b, l2b, w.bfc1, 4 * D, D, st));
         TRY(g->alloc(&w.cfc1, (size_t)4 * D));
         TRY(fold_bias(f1w, nullptr, l2w, w.cfc1, 4 * D, D, st));
         TRY(g->alloc(&w.wfc2, (size_t)4 * D * D / 4));
-        TRY(pack(g, f2w, w.wfc2, D, 4 * D, 0, st));
+        TRY(pack(f2w, w.wfc2, D, 4 * D, 0, st));
         TRY(copy_vec(g, &w.bfc2, f2b, D, st));
     }
     const size_t Mpad = (size_t)g->MTmax * 32;

@@ -1,0 +1,508 @@
+// RAR generator decode engine for gfx950 (fp32, exact-f32 MFMA) -- SURVEY.md section 8a row R1.
+//
+// Reference: deps/rar/modeling/rar.py:56-118 (Attention with qk-norm and KV cache), :138-183
+// (adaLN Block), :123-134 (FinalLayer), :319-405 (forward_fn), :408-459 (generate with
+// classifier-free guidance).
+//
+// Same building blocks and data layout as gpt.hip (decoder_kernels.h): fragment-packed weights
+// and activations, split-K slabs, fp64 LayerNorm partial sums.  What is specific to RAR:
+//   * every row carries a condition vector c = emb[cond] + timestep[p]; SiLU(c) feeds ONE GEMM per
+//     position that produces the adaLN shift/scale/gate of all blocks and of the final layer
+//     ([M, 6d*L + 2d], row-major);
+//   * LayerNorm outputs are modulated per row AND per channel (x*(1+scale)+shift), so the
+//     normalised activation is written explicitly (k_modulate) instead of being folded into the
+//     weights; residual updates are gated (k_resid_stats with a gate);
+//   * q and k are LayerNorm-ed per head inside the attention prologue; head_dim may be 80;
+//   * classifier-free guidance doubles the batch: rows [0,B) conditional, [B,2B) unconditional,
+//     mixed inside the fused sampler;
+//   * position 0 holds the cls token, position 1 the condition token: 257 positions per image.
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "decoder_host.h"
+
+namespace wmar {
+
+// x0 = token vector + pos_embed[p] (+ target_aware_pos_embed[p+1] for p >= 1), LN partial sums;
+// sc = SiLU(emb[cond] + timesteps[p])   (forward_fn, rar.py:346-384)
+struct RarEmbedArgs {
+    float4* x; float4* sc; double* stats;
+    const float* emb;        // [n_embeddings][d]
+    const float* cls;        // [d]
+    const float* pos; const float* tape; const float* tstep;   // [*][d]
+    const long long* tok;    // explicit token per row (forward_position) or null
+    const long long* cond;   // [M] condition id per row
+    const long long* ids;    // [B][ids_stride] generated ids (generate)
+    long long ids_stride;
+    const int* pos_dev;
+    int KB, MT, n_chunks, M, Bhalf, K;
+};
+
+static __global__ __launch_bounds__(256) void k_rar_embed(RarEmbedArgs a) {
+    constexpr int KPW = 4;
+    __shared__ double red[4][32][2];
+    const int c = blockIdx.x / a.MT, mt = blockIdx.x % a.MT;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int kb0 = (int)((unsigned)c * (unsigned)a.KB / (unsigned)a.n_chunks);
+    const int kb1 = (int)((unsigned)(c + 1) * (unsigned)a.KB / (unsigned)a.n_chunks);
+    const int m = mt * 32 + (lane & 31), half = lane >> 5;
+    const int p = *a.pos_dev;
+    const int mm = m < a.M ? m : 0;
+    long long tk;
+    if (a.tok) tk = a.tok[mm];
+    else if (p == 0) tk = -1;
+    else if (p == 1) tk = a.cond[mm];
+    else tk = a.ids[(long long)(mm % a.Bhalf) * a.ids_stride + (p - 2)];
+    const float* trow = tk < 0 ? a.cls : a.emb + tk * a.K;
+    const float* crow = a.emb + a.cond[mm] * a.K;
+    const float* prow = a.pos + (long long)p * a.K;
+    const float* arow = a.tape + (long long)(p + 1) * a.K;
+    const float* srow = a.tstep + (long long)p * a.K;
+    double s = 0.0, ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        const int kb = kb0 + w + 4 * i;
+        if (kb >= kb1) continue;
+        const int k = kb * 8 + 4 * half;
+        const long long idx = ((long long)kb * a.MT + mt) * 64 + lane;
+        float4 t = *(const float4*)(trow + k), pe = *(const float4*)(prow + k);
+        float4 r = make_float4(t.x + pe.x, t.y + pe.y, t.z + pe.z, t.w + pe.w);
+        if (p >= 1) {
+            float4 ta = *(const float4*)(arow + k);
+            r.x += ta.x; r.y += ta.y; r.z += ta.z; r.w += ta.w;
+        }
+        a.x[idx] = r;
+        s += (double)r.x + (double)r.y + (double)r.z + (double)r.w;
+        ss += (double)r.x * r.x + (double)r.y * r.y + (double)r.z * r.z + (double)r.w * r.w;
+        float4 ce = *(const float4*)(crow + k), te = *(const float4*)(srow + k);
+        float cv[4] = {ce.x + te.x, ce.y + te.y, ce.z + te.z, ce.w + te.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cv[j] = cv[j] / (1.0f + expf(-cv[j]));   // SiLU
+        a.sc[idx] = make_float4(cv[0], cv[1], cv[2], cv[3]);
+    }
+    s += __shfl_xor(s, 32);
+    ss += __shfl_xor(ss, 32);
+    if (lane < 32) { red[w][lane][0] = s; red[w][lane][1] = ss; }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double ts = 0, tss = 0;
+        for (int i = 0; i < 4; ++i) { ts += red[i][threadIdx.x][0]; tss += red[i][threadIdx.x][1]; }
+        double* o = a.stats + ((long long)c * a.MT * 32 + mt * 32 + threadIdx.x) * 2;
+        o[0] = ts; o[1] = tss;
+    }
+}
+
+// h = LayerNorm(x; gamma, beta, eps 1e-6) * (1 + scale) + shift      (modulate, rar.py:120-121)
+// gamma/beta null: no affine (FinalLayer.norm_final).  scale/shift: row-major [M][mod_stride].
+struct ModArgs {
+    const float4* x; float4* h; const double* stats;
+    const float* gamma; const float* beta;
+    const float* shift; const float* scale; long long mod_stride;
+    int KB, MT, n_chunks, K;
+};
+
+static __global__ __launch_bounds__(256) void k_modulate(ModArgs a) {
+    const int c = blockIdx.x / a.MT, mt = blockIdx.x % a.MT;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int kb0 = (int)((unsigned)c * (unsigned)a.KB / (unsigned)a.n_chunks);
+    const int kb1 = (int)((unsigned)(c + 1) * (unsigned)a.KB / (unsigned)a.n_chunks);
+    const int m = mt * 32 + (lane & 31), half = lane >> 5;
+    float mu, rstd;
+    {   // eps 1e-6 (RAR's norm_layer); ln_row_stats uses 1e-5, so finish the statistics here
+        double sm = 0, sq = 0;
+        for (int c0 = 0; c0 < a.n_chunks; c0 += 16) {
+            double2 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = *(const double2*)(a.stats + ((long long)min(c0 + i, a.n_chunks - 1) * a.MT * 32 + m) * 2);
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (c0 + i < a.n_chunks) { sm += v[i].x; sq += v[i].y; }
+        }
+        const double invK = 1.0 / (double)a.K;
+        const double mean = sm * invK;
+        mu = (float)mean;
+        rstd = rsqrtf((float)(sq * invK - mean * mean) + 1e-6f);
+    }
+    for (int kb = kb0 + w; kb < kb1; kb += 4) {
+        const int k = kb * 8 + 4 * half;
+        const long long idx = ((long long)kb * a.MT + mt) * 64 + lane;
+        const float4 v = a.x[idx];
+        float r[4] = {(v.x - mu) * rstd, (v.y - mu) * rstd, (v.z - mu) * rstd, (v.w - mu) * rstd};
+        if (a.gamma) {
+            const float4 g = *(const float4*)(a.gamma + k), bt = *(const float4*)(a.beta + k);
+            r[0] = r[0] * g.x + bt.x; r[1] = r[1] * g.y + bt.y; r[2] = r[2] * g.z + bt.z; r[3] = r[3] * g.w + bt.w;
+        }
+        const float4 sc = *(const float4*)(a.scale + (long long)m * a.mod_stride + k);
+        const float4 sh = *(const float4*)(a.shift + (long long)m * a.mod_stride + k);
+        a.h[idx] = make_float4(r[0] * (1.0f + sc.x) + sh.x, r[1] * (1.0f + sc.y) + sh.y, r[2] * (1.0f + sc.z) + sh.z,
+                               r[3] * (1.0f + sc.w) + sh.w);
+    }
+}
+
+// tok_out[b] replicated to the unconditional half happens implicitly: ids are shared by b % B.
+static __global__ void k_set3(int* p, int a, int b, int c) { p[0] = a; p[1] = b; p[2] = c; }
+
+}  // namespace wmar
+
+using namespace wmar;
+
+struct RarLayer {
+    float4 *wqkv, *wproj, *wfc1, *wfc2;
+    float *bqkv, *bproj, *bfc1, *bfc2, *n1w, *n1b, *n2w, *n2b, *qnw, *qnb, *knw, *knb;
+};
+
+struct wmar_rar {
+    wmar_rar_config cfg{};
+    DeviceArena mem;
+    int D = 0, H = 0, hd = 0, V = 0, L = 0, F = 0, T = 0, Bmax = 0, Mmax = 0, MTmax = 0;
+    long long Ntot = 0;
+    std::vector<RarLayer> layers;
+    float *emb = nullptr, *cls = nullptr, *pos = nullptr, *tape = nullptr, *tstep = nullptr;
+    float4 *wada = nullptr, *whead = nullptr;
+    float *bada = nullptr, *bhead = nullptr;
+    // workspaces
+    float4 *x = nullptr, *h = nullptr, *y = nullptr, *hbuf = nullptr, *sc = nullptr, *slabs = nullptr, *qkv_slabs = nullptr;
+    float* mod = nullptr;
+    double* stats = nullptr;
+    float *kcache = nullptr, *vcache = nullptr, *logits = nullptr, *scratch = nullptr, *cfg_scale = nullptr;
+    long long *ids = nullptr, *cond_ids = nullptr;
+    int* ctr = nullptr;   // [pos, step, len]
+    hipStream_t cap_stream = nullptr;
+    hipEvent_t ev = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool pending = false;
+    void drop_graph() {
+        if (pending && ev) (void)hipEventSynchronize(ev);
+        pending = false;
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        exec = nullptr; graph = nullptr;
+    }
+    template <typename Tp>
+    int alloc(Tp** p, size_t n) { return mem.alloc(p, n); }
+    ~wmar_rar() {
+        drop_graph();
+        mem.release();
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
+        if (ev) (void)hipEventDestroy(ev);
+    }
+};
+
+namespace {
+
+struct RarPlan {
+    wmar_rar* g;
+    int M, Bhalf;           // rows this call (2B with guidance), B
+    hipStream_t st;
+    int MT, D, KBD, KBF, nch;
+    long long act;
+    int S_proj, S_fc2;
+    const long long* tok;   // explicit tokens (forward_position) or null
+
+    RarPlan(wmar_rar* g_, int M_, int Bhalf_, const long long* tok_, hipStream_t st_) : g(g_), M(M_), Bhalf(Bhalf_), st(st_), tok(tok_) {
+        MT = mt_for(M); D = g->D; KBD = D / 8; KBF = g->F / 8; nch = stat_chunks(KBD);
+        act = (long long)KBD * MT * 64;
+        const int tiles = MT % 2 == 0 ? (D / 32) * (MT / 2) : (D / 32) * MT;
+        S_proj = pick_split(tiles, KBD, 4);
+        S_fc2 = pick_split(tiles, KBF, 4);
+    }
+    GemmArgs base() const {
+        GemmArgs a{};
+        a.MT = MT; a.B = M; a.stats = g->stats; a.n_chunks = nch; a.K = D;
+        a.pos_dev = g->ctr; a.D = D; a.H = g->H; a.hd = g->hd; a.Tmax = g->T;
+        return a;
+    }
+    int embed() {
+        RarEmbedArgs e{};
+        e.x = g->x; e.sc = g->sc; e.stats = g->stats; e.emb = g->emb; e.cls = g->cls; e.pos = g->pos; e.tape = g->tape;
+        e.tstep = g->tstep; e.tok = tok; e.cond = g->cond_ids; e.ids = g->ids; e.ids_stride = g->cfg.image_seq_len;
+        e.pos_dev = g->ctr; e.KB = KBD; e.MT = MT; e.n_chunks = nch; e.M = M; e.Bhalf = Bhalf; e.K = D;
+        hipLaunchKernelGGL(k_rar_embed, dim3(nch * MT), dim3(256), 0, st, e);
+        return launch_status("k_rar_embed");
+    }
+    // all adaLN modulations of this position: mod[M][Ntot] = SiLU(c) W_ada^T + b_ada
+    int adaln() {
+        GemmArgs a = base();
+        a.Wp = g->wada; a.Xp = g->sc; a.KB = KBD; a.NT = (int)(g->Ntot / 32); a.bias = g->bada;
+        a.logits = g->mod; a.V = (int)g->Ntot;
+        return gemm_dispatch<EPI_LOGITS, false>(a, false, st);
+    }
+    int modulate(const float* gamma, const float* beta, long long off_shift, long long off_scale) {
+        ModArgs m{};
+        m.x = g->x; m.h = g->h; m.stats = g->stats; m.gamma = gamma; m.beta = beta;
+        m.shift = g->mod + off_shift; m.scale = g->mod + off_scale; m.mod_stride = g->Ntot;
+        m.KB = KBD; m.MT = MT; m.n_chunks = nch; m.K = D;
+        hipLaunchKernelGGL(k_modulate, dim3(nch * MT), dim3(256), 0, st, m);
+        return launch_status("k_modulate");
+    }
+    int resid(const float* bias, int S, long long off_gate) {
+        ResidArgs r{};
+        r.x = g->x; r.stats = g->stats; r.KB = KBD; r.MT = MT; r.n_chunks = nch; r.B = M; r.K = D;
+        r.slabs = g->slabs; r.slab_stride = act; r.S = S; r.bias = bias;
+        r.gate = g->mod + off_gate; r.gate_stride = g->Ntot;
+        return launch_resid(r, nch * MT, st);
+    }
+    int layer(int l) {
+        const RarLayer& w = g->layers[l];
+        const long long o = (long long)l * 6 * D;   // chunk(6): shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+        int rc, S = 1;
+        if ((rc = modulate(w.n1w, w.n1b, o, o + D))) return rc;
+        GemmArgs a = base();
+        a.Wp = w.wqkv; a.Xp = g->h; a.KB = KBD; a.NT = 3 * D / 32; a.out_packed = g->qkv_slabs; a.slab_stride = 3 * act;
+        if ((rc = gemm_split(a, &S, st, 1))) return rc;
+        AttnArgs t{};
+        const long long lstride = (long long)g->Mmax * g->H * g->T * g->hd;
+        t.qkv_slabs = g->qkv_slabs; t.slab_stride = 3 * act; t.S = 1; t.stats = g->stats; t.n_chunks = nch; t.K = D;
+        t.bias = w.bqkv; t.mode = 1; t.qn_w = w.qnw; t.qn_b = w.qnb; t.kn_w = w.knw; t.kn_b = w.knb;
+        t.kcache = g->kcache + l * lstride; t.vcache = g->vcache + l * lstride; t.y = g->y; t.pos_dev = g->ctr;
+        t.D = D; t.H = g->H; t.Tmax = g->T; t.MT = MT; t.scale = 1.0f / sqrtf((float)g->hd);
+        const dim3 grid((unsigned)(M * g->H));
+        switch (g->hd) {
+            case 32: hipLaunchKernelGGL((k_attn_decode<32, 2>), grid, dim3(128), 0, st, t); break;
+            case 48: hipLaunchKernelGGL((k_attn_decode<48, 2>), grid, dim3(128), 0, st, t); break;
+            case 64: hipLaunchKernelGGL((k_attn_decode<64, 2>), grid, dim3(128), 0, st, t); break;
+            case 80: hipLaunchKernelGGL((k_attn_decode<80, 2>), grid, dim3(128), 0, st, t); break;
+            case 88: hipLaunchKernelGGL((k_attn_decode<88, 2>), grid, dim3(128), 0, st, t); break;
+            default: hipLaunchKernelGGL((k_attn_decode<128, 2>), grid, dim3(128), 0, st, t); break;
+        }
+        if ((rc = launch_status("k_attn_decode"))) return rc;
+        GemmArgs p = base();
+        p.Wp = w.wproj; p.Xp = g->y; p.KB = KBD; p.NT = D / 32; p.out_packed = g->slabs; p.slab_stride = act;
+        if ((rc = gemm_split(p, &S, st, S_proj))) return rc;
+        if ((rc = resid(w.bproj, S_proj, o + 2 * D))) return rc;
+        if ((rc = modulate(w.n2w, w.n2b, o + 3 * D, o + 4 * D))) return rc;
+        GemmArgs f = base();
+        f.Wp = w.wfc1; f.Xp = g->h; f.bias = w.bfc1; f.KB = KBD; f.NT = g->F / 32; f.out_packed = g->hbuf;
+        if ((rc = gemm_dispatch<EPI_GELU, false>(f, false, st))) return rc;
+        GemmArgs q = base();
+        q.Wp = w.wfc2; q.Xp = g->hbuf; q.KB = KBF; q.NT = D / 32; q.out_packed = g->slabs; q.slab_stride = act;
+        if ((rc = gemm_split(q, &S, st, S_fc2))) return rc;
+        return resid(w.bfc2, S_fc2, o + 5 * D);
+    }
+    int head(float* logits_out) {
+        const long long o = (long long)g->L * 6 * D;   // FinalLayer: scale first, then shift (rar.py:132)
+        int rc;
+        if ((rc = modulate(nullptr, nullptr, o + D, o))) return rc;
+        GemmArgs a = base();
+        a.Wp = g->whead; a.Xp = g->h; a.KB = KBD; a.NT = g->V / 32; a.bias = g->bhead; a.logits = logits_out; a.V = g->V;
+        return gemm_dispatch<EPI_LOGITS, false>(a, false, st);
+    }
+    int position(bool with_head, float* logits_out) {
+        int rc;
+        if ((rc = embed())) return rc;
+        if ((rc = adaln())) return rc;
+        for (int l = 0; l < g->L; ++l)
+            if ((rc = layer(l))) return rc;
+        return with_head ? head(logits_out) : WMAR_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int wmar_rar_create(const wmar_rar_config* cfg, const char* const* names, const void* const* tensors_dev,
+                    int32_t n_tensors, void* stream, wmar_rar** out) {
+    WMAR_REQUIRE(cfg && names && tensors_dev && out, "rar_create: null argument");
+    const int D = cfg->hidden_size, H = cfg->num_attention_heads, L = cfg->num_hidden_layers, F = cfg->intermediate_size;
+    const int V = cfg->codebook_size;
+    WMAR_REQUIRE(D % H == 0, "hidden_size %% heads != 0");
+    const int hd = D / H;
+    WMAR_REQUIRE(D % 32 == 0 && F % 32 == 0 && V % 32 == 0 && D <= 8192, "hidden (<=8192), intermediate and codebook sizes must be multiples of 32");
+    WMAR_REQUIRE(hd == 32 || hd == 48 || hd == 64 || hd == 80 || hd == 88 || hd == 128, "head_dim %d unsupported", hd);
+    WMAR_REQUIRE(cfg->max_batch >= 1 && cfg->max_batch <= 64, "max_batch must be in 1..64 (rows double under guidance)");
+    TensorMap tm;
+    for (int i = 0; i < n_tensors; ++i) tm.m[names[i]] = tensors_dev[i];
+    hipStream_t st = (hipStream_t)stream;
+    auto* g = new wmar_rar();
+    g->cfg = *cfg; g->D = D; g->H = H; g->hd = hd; g->V = V; g->L = L; g->F = F;
+    g->T = cfg->image_seq_len + 2; g->Bmax = cfg->max_batch; g->Mmax = 2 * cfg->max_batch; g->MTmax = mt_for(g->Mmax);
+    g->Ntot = (long long)6 * D * L + 2 * D;
+    int rc = WMAR_OK;
+    auto need = [&](const std::string& k) -> const float* {
+        const float* p = tm.get(k);
+        if (!p && rc == WMAR_OK) { set_error("checkpoint tensor '%s' is missing", k.c_str()); rc = WMAR_EMISSING; }
+        return p;
+    };
+#define TRY(x) do { if (rc == WMAR_OK) rc = (x); } while (0)
+    const int nemb = V + 1 + cfg->condition_num_classes + 1;
+    const float *e = need("embeddings.weight"), *cl = need("cls_token"), *pe = need("pos_embed"),
+                *ta = need("target_aware_pos_embed"), *ts = need("timesteps_embeddings"), *hw = need("lm_head.weight"),
+                *hb = need("lm_head.bias"), *fw = need("adaln_before_head.adaLN_modulation.1.weight"),
+                *fb = need("adaln_before_head.adaLN_modulation.1.bias");
+    if (rc == WMAR_OK) {
+        TRY(copy_vec(g, &g->emb, e, (size_t)nemb * D, st));
+        TRY(copy_vec(g, &g->cls, cl, (size_t)D, st));
+        TRY(copy_vec(g, &g->pos, pe, (size_t)(cfg->image_seq_len + 1024) * D, st));
+        TRY(copy_vec(g, &g->tape, ta, (size_t)(cfg->image_seq_len + 1024) * D, st));
+        TRY(copy_vec(g, &g->tstep, ts, (size_t)(cfg->image_seq_len + 100) * D, st));
+        TRY(g->alloc(&g->whead, (size_t)V * D / 4));
+        TRY(pack(hw, g->whead, V, D, 0, st));
+        TRY(copy_vec(g, &g->bhead, hb, (size_t)V, st));
+        TRY(g->alloc(&g->wada, (size_t)g->Ntot * D / 4));
+        TRY(g->alloc(&g->bada, (size_t)g->Ntot));
+    }
+    g->layers.resize(L);
+    for (int l = 0; l < L && rc == WMAR_OK; ++l) {
+        const std::string p = "blocks." + std::to_string(l) + ".";
+        RarLayer& w = g->layers[l];
+        const float *qw = need(p + "attn.qkv.weight"), *qb = need(p + "attn.qkv.bias"), *pw = need(p + "attn.proj.weight"),
+                    *pb = need(p + "attn.proj.bias"), *f1w = need(p + "mlp.fc1.weight"), *f1b = need(p + "mlp.fc1.bias"),
+                    *f2w = need(p + "mlp.fc2.weight"), *f2b = need(p + "mlp.fc2.bias"), *n1w = need(p + "norm1.weight"),
+                    *n1b = need(p + "norm1.bias"), *n2w = need(p + "norm2.weight"), *n2b = need(p + "norm2.bias"),
+                    *qnw = need(p + "attn.q_norm.weight"), *qnb = need(p + "attn.q_norm.bias"),
+                    *knw = need(p + "attn.k_norm.weight"), *knb = need(p + "attn.k_norm.bias"),
+                    *aw = need(p + "adaLN_modulation.1.weight"), *ab = need(p + "adaLN_modulation.1.bias");
+        if (rc != WMAR_OK) break;
+        TRY(g->alloc(&w.wqkv, (size_t)3 * D * D / 4)); TRY(pack(qw, w.wqkv, 3 * D, D, 0, st));
+        TRY(copy_vec(g, &w.bqkv, qb, (size_t)3 * D, st));
+        TRY(g->alloc(&w.wproj, (size_t)D * D / 4)); TRY(pack(pw, w.wproj, D, D, 0, st));
+        TRY(copy_vec(g, &w.bproj, pb, (size_t)D, st));
+        TRY(g->alloc(&w.wfc1, (size_t)F * D / 4)); TRY(pack(f1w, w.wfc1, F, D, 0, st));
+        TRY(copy_vec(g, &w.bfc1, f1b, (size_t)F, st));
+        TRY(g->alloc(&w.wfc2, (size_t)F * D / 4)); TRY(pack(f2w, w.wfc2, D, F, 0, st));
+        TRY(copy_vec(g, &w.bfc2, f2b, (size_t)D, st));
+        TRY(copy_vec(g, &w.n1w, n1w, (size_t)D, st)); TRY(copy_vec(g, &w.n1b, n1b, (size_t)D, st));
+        TRY(copy_vec(g, &w.n2w, n2w, (size_t)D, st)); TRY(copy_vec(g, &w.n2b, n2b, (size_t)D, st));
+        TRY(copy_vec(g, &w.qnw, qnw, (size_t)hd, st)); TRY(copy_vec(g, &w.qnb, qnb, (size_t)hd, st));
+        TRY(copy_vec(g, &w.knw, knw, (size_t)hd, st)); TRY(copy_vec(g, &w.knb, knb, (size_t)hd, st));
+        // this block's 6d adaLN rows go to their slice of the one big modulation GEMM
+        TRY(pack(aw, g->wada, 6 * D, D, l * (6 * D / 32), st));
+        if (rc == WMAR_OK && hipMemcpyAsync(g->bada + (size_t)l * 6 * D, ab, (size_t)6 * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            set_error("adaLN bias copy failed"); rc = WMAR_EHIP;
+        }
+    }
+    if (rc == WMAR_OK) {
+        TRY(pack(fw, g->wada, 2 * D, D, L * (6 * D / 32), st));
+        if (rc == WMAR_OK && hipMemcpyAsync(g->bada + (size_t)L * 6 * D, fb, (size_t)2 * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            set_error("final adaLN bias copy failed"); rc = WMAR_EHIP;
+        }
+    }
+    const size_t Mpad = (size_t)g->MTmax * 32;
+    TRY(g->alloc(&g->x, Mpad * D / 4));
+    TRY(g->alloc(&g->h, Mpad * D / 4));
+    TRY(g->alloc(&g->y, Mpad * D / 4));
+    TRY(g->alloc(&g->sc, Mpad * D / 4));
+    TRY(g->alloc(&g->hbuf, Mpad * F / 4));
+    TRY(g->alloc(&g->slabs, (size_t)MAX_SLABS * Mpad * D / 4));
+    TRY(g->alloc(&g->qkv_slabs, Mpad * 3 * D / 4));
+    TRY(g->alloc(&g->mod, Mpad * (size_t)g->Ntot));
+    TRY(g->alloc(&g->stats, (size_t)STAT_CHUNKS_MAX * Mpad * 2));
+    const size_t kv = (size_t)L * g->Mmax * H * g->T * hd;
+    TRY(g->alloc(&g->kcache, kv));
+    TRY(g->alloc(&g->vcache, kv));
+    TRY(g->alloc(&g->logits, (size_t)g->Mmax * V));
+    TRY(g->alloc(&g->scratch, (size_t)g->Bmax * V));
+    TRY(g->alloc(&g->cfg_scale, (size_t)cfg->image_seq_len));
+    TRY(g->alloc(&g->ids, (size_t)g->Bmax * cfg->image_seq_len));
+    TRY(g->alloc(&g->cond_ids, (size_t)g->Mmax));
+    TRY(g->alloc(&g->ctr, 4));
+    if (rc == WMAR_OK) {
+        hipError_t er = hipMemsetAsync(g->x, 0, Mpad * D * 4, st);
+        if (er == hipSuccess) er = hipMemsetAsync(g->h, 0, Mpad * D * 4, st);
+        if (er == hipSuccess) er = hipMemsetAsync(g->y, 0, Mpad * D * 4, st);
+        if (er == hipSuccess) er = hipMemsetAsync(g->sc, 0, Mpad * D * 4, st);
+        if (er == hipSuccess) er = hipMemsetAsync(g->hbuf, 0, Mpad * F * 4, st);
+        if (er == hipSuccess) er = hipMemsetAsync(g->mod, 0, Mpad * (size_t)g->Ntot * 4, st);
+        if (er == hipSuccess) er = hipMemsetAsync(g->kcache, 0, kv * 4, st);
+        if (er == hipSuccess) er = hipMemsetAsync(g->vcache, 0, kv * 4, st);
+        if (er == hipSuccess) er = hipMemsetAsync(g->ids, 0, (size_t)g->Bmax * cfg->image_seq_len * 8, st);
+        if (er == hipSuccess) er = hipMemsetAsync(g->cond_ids, 0, (size_t)g->Mmax * 8, st);
+        if (er == hipSuccess) er = hipStreamCreateWithFlags(&g->cap_stream, hipStreamNonBlocking);
+        if (er == hipSuccess) er = hipEventCreate(&g->ev);
+        if (er == hipSuccess) er = hipStreamSynchronize(st);
+        if (er != hipSuccess) { set_error("rar_create: %s", hipGetErrorString(er)); rc = WMAR_EHIP; }
+    }
+#undef TRY
+    if (rc != WMAR_OK) { delete g; return rc; }
+    *out = g;
+    return WMAR_OK;
+}
+
+void wmar_rar_destroy(wmar_rar* g) { delete g; }
+int64_t wmar_rar_device_bytes(const wmar_rar* g) { return g ? g->mem.bytes : 0; }
+
+int wmar_rar_forward_position(wmar_rar* g, const int64_t* tok_dev, const int64_t* cond_ids_dev, int64_t M, int32_t pos,
+                              float* logits_dev, void* stream) {
+    WMAR_REQUIRE(g && tok_dev && cond_ids_dev && logits_dev, "rar_forward_position: null argument");
+    WMAR_REQUIRE(M >= 1 && M <= g->Mmax, "rar_forward_position: rows %lld outside 1..%d", (long long)M, g->Mmax);
+    WMAR_REQUIRE(pos >= 0 && pos < g->T, "rar_forward_position: position %d outside 0..%d", pos, g->T - 1);
+    hipStream_t st = (hipStream_t)stream;
+    WMAR_HIP_CHECK(hipMemcpyAsync(g->cond_ids, cond_ids_dev, (size_t)M * 8, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_set3, dim3(1), dim3(1), 0, st, g->ctr, (int)pos, 0, 0);
+    RarPlan p(g, (int)M, (int)M, (const long long*)tok_dev, st);
+    return p.position(true, logits_dev);
+}
+
+int wmar_rar_generate(wmar_rar* g, const wmar_wm_ctx* wm, const int64_t* class_ids_dev, int64_t B,
+                      const float* cfg_scale_host, int32_t use_guidance, float temperature, const float* q_dev,
+                      int64_t* tokens_out_dev, int32_t use_graph, void* stream) {
+    WMAR_REQUIRE(g && class_ids_dev && q_dev && tokens_out_dev, "rar_generate: null argument");
+    WMAR_REQUIRE(B >= 1 && B <= g->Bmax, "rar_generate: batch %lld outside 1..%d", (long long)B, g->Bmax);
+    WMAR_REQUIRE(!use_guidance || cfg_scale_host, "rar_generate: guidance scales missing");
+    if (wm) WMAR_REQUIRE(wm->table_dev && wm->vocab_size == g->V, "rar_generate: watermark vocab mismatch");
+    hipStream_t st = (hipStream_t)stream;
+    const int L = g->cfg.image_seq_len, V = g->V;
+    const int M = use_guidance ? 2 * (int)B : (int)B;
+    g->drop_graph();
+    // condition ids: class + codebook_size + 1, unconditional rows get the "none" id (rar.py:303-312)
+    std::vector<long long> hc((size_t)B);
+    WMAR_HIP_CHECK(hipMemcpyAsync(hc.data(), class_ids_dev, (size_t)B * 8, hipMemcpyDeviceToHost, st));
+    WMAR_HIP_CHECK(hipStreamSynchronize(st));
+    std::vector<long long> ci((size_t)M);
+    const long long none_id = (long long)g->cfg.condition_num_classes + V + 1;
+    for (int b = 0; b < (int)B; ++b) {
+        WMAR_REQUIRE(hc[b] >= 0 && hc[b] < g->cfg.condition_num_classes, "class id %lld out of range", hc[b]);
+        ci[b] = hc[b] + V + 1;
+        if (use_guidance) ci[B + b] = none_id;
+    }
+    WMAR_HIP_CHECK(hipMemcpyAsync(g->cond_ids, ci.data(), (size_t)M * 8, hipMemcpyHostToDevice, st));
+    if (use_guidance) WMAR_HIP_CHECK(hipMemcpyAsync(g->cfg_scale, cfg_scale_host, (size_t)L * 4, hipMemcpyHostToDevice, st));
+    WMAR_HIP_CHECK(hipStreamSynchronize(st));   // host staging vectors go out of scope
+
+    RarPlan p(g, M, (int)B, nullptr, st);
+    // position 0: the cls token (no logits needed)
+    hipLaunchKernelGGL(k_set3, dim3(1), dim3(1), 0, st, g->ctr, 0, 0, 0);
+    if (int rc = p.position(false, nullptr)) return rc;
+    hipLaunchKernelGGL(k_set3, dim3(1), dim3(1), 0, st, g->ctr, 1, 0, 0);   // pos = 1, step = 0, len(ids) = 0
+
+    SampArgs a{};
+    a.wm = make_wm(wm);
+    a.logits = g->logits; a.V = V; a.past = g->ids; a.past_stride = L; a.t_dev = g->ctr + 2;
+    a.temperature = temperature; a.top_k = 0; a.use_top_p = 0; a.top_p_thr = 0.f;
+    a.q = q_dev; a.q_step_stride = (long long)B * V; a.step_dev = g->ctr + 1;
+    a.scratch = g->scratch; a.tok_out = (long long*)tokens_out_dev; a.tok_out_stride = L;
+    a.past_append = g->ids; a.trace = nullptr; a.B = B;
+    if (use_guidance) { a.logits_uncond = g->logits + (long long)B * V; a.cfg_scale = g->cfg_scale; }
+
+    auto one_step = [&](hipStream_t s) -> int {
+        RarPlan q(g, M, (int)B, nullptr, s);
+        int rc = q.position(true, g->logits);
+        if (rc) return rc;
+        if ((rc = launch_sample_fused(a, s))) return rc;
+        hipLaunchKernelGGL(k_advance3, dim3(1), dim3(1), 0, s, g->ctr);
+        return launch_status("k_advance3");
+    };
+    if (use_graph) {
+        WMAR_HIP_CHECK(hipStreamBeginCapture(g->cap_stream, hipStreamCaptureModeThreadLocal));
+        int rc = one_step(g->cap_stream);
+        hipError_t e = hipStreamEndCapture(g->cap_stream, &g->graph);
+        if (rc) { g->drop_graph(); return rc; }
+        if (e != hipSuccess) { g->drop_graph(); set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return WMAR_EHIP; }
+        e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) { g->drop_graph(); set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return WMAR_EHIP; }
+        for (int n = 0; n < L && e == hipSuccess; ++n) e = hipGraphLaunch(g->exec, st);
+        if (e == hipSuccess) e = hipEventRecord(g->ev, st);
+        if (e != hipSuccess) { set_error("graph replay failed: %s", hipGetErrorString(e)); return WMAR_EHIP; }
+        g->pending = true;
+    } else {
+        for (int n = 0; n < L; ++n)
+            if (int rc = one_step(st)) return rc;
+    }
+    return WMAR_OK;
+}
+
+}  // extern "C"

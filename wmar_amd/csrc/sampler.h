@@ -49,6 +49,9 @@ struct SampArgs {
     long long* past_append;      // nullable: past[b*past_stride + t] = token
     float* trace;                // nullable: raw logits copy [steps][B][V]
     long long B;
+    // classifier-free guidance (RAR.generate, rar.py:437-442): logits = uncond + (cond - uncond) * scale[step]
+    const float* logits_uncond;  // nullable [B, V]
+    const float* cfg_scale;      // device float [steps]
 };
 
 int launch_sample_fused(const SampArgs& a, hipStream_t st);

@@ -133,6 +133,8 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
     const long long* past = a.past ? a.past + b * a.past_stride : nullptr;
     const uint32_t* grow = past ? wm_row(a.wm, past, t) : nullptr;
     const float* lg = a.logits + b * V;
+    const float* ul = a.logits_uncond ? a.logits_uncond + b * V : nullptr;
+    const float cfg = ul ? a.cfg_scale[step] : 0.f;
     const float* q = a.q + step * a.q_step_stride + b * V;
     float* x = a.scratch + b * V;
     float* trace = a.trace ? a.trace + (step * a.B + b) * V : nullptr;
@@ -158,6 +160,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
         for (int i = 0; i < (EPT > 0 ? EPT : 1); ++i) {
             const long long v = tid + (long long)i * SAMP_THREADS;
             lv[i] = v < V ? lg[v] : 0.f;
+            if (ul && v < V) { const float u = ul[v]; const float dlt = lv[i] - u; const float sc = dlt * cfg; lv[i] = u + sc; }
         }
 #pragma unroll
         for (int i = 0; i < (EPT > 0 ? EPT : 1); ++i) {
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
     } else {
         for (long long v = tid; v < V; v += SAMP_THREADS) {
             float xv = lg[v];
+            if (ul) { const float u = ul[v]; const float dlt = xv - u; const float sc = dlt * cfg; xv = u + sc; }
             if (trace) trace[v] = xv;
             if (grow && ((grow[v >> 5] >> (v & 31)) & 1u)) xv = xv + delta;
             xv = xv / T;

@@ -168,3 +168,67 @@ class VQGANEngine:
                     self._h, images[b0:b1].data_ptr(), b1 - b0, codes[b0:b1].data_ptr(),
                     pre[b0 * S * S:b1 * S * S].data_ptr() if pre is not None else None, _lib.stream_ptr(self.device)))
         return (codes, pre) if return_prequant else codes
+
+
+class RAREngine:
+    """RAR generator with KV cache, adaLN, qk-norm and classifier-free guidance; replaces
+    RAR.forward_fn / RAR.generate (deps/rar/modeling/rar.py:319-459)."""
+
+    def __init__(self, cfg, state: Dict[str, torch.Tensor], max_batch: int = 64, device="cuda"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.max_batch = int(max_batch)
+        L = _lib.load()
+        tensors = {k: v.detach().to(device=self.device, dtype=torch.float32).contiguous() for k, v in state.items()
+                   if k != "attn_mask"}
+        names, ptrs, n = _lib.tensor_table(tensors)
+        c = _lib.RarConfig(cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.intermediate_size,
+                           cfg.image_seq_len, cfg.codebook_size, cfg.condition_num_classes, self.max_batch)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(L.wmar_rar_create(C.byref(c), names, ptrs, n, _lib.stream_ptr(self.device), C.byref(h)))
+        self._h = h
+        self._L = L
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.wmar_rar_destroy(h)
+            self._h = None
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self._L.wmar_rar_device_bytes(self._h))
+
+    def forward_position(self, tok: torch.Tensor, cond_ids: torch.Tensor, pos: int) -> torch.Tensor:
+        """tok int64 [M] (-1 = cls), cond_ids int64 [M] (offset condition ids) -> logits [M, V]."""
+        _require_cuda(tok, "tokens")
+        tok = tok.to(torch.int64).contiguous().view(-1)
+        cond_ids = cond_ids.to(device=self.device, dtype=torch.int64).contiguous().view(-1)
+        M = tok.shape[0]
+        logits = torch.empty(M, self.cfg.codebook_size, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.wmar_rar_forward_position(self._h, tok.data_ptr(), cond_ids.data_ptr(), M, int(pos),
+                                                         logits.data_ptr(), _lib.stream_ptr(self.device)))
+        return logits
+
+    def generate(self, class_ids: torch.Tensor, q: torch.Tensor, cfg_scales: Optional[torch.Tensor], temperature=1.0,
+                 wm_ctx: Optional[_lib.WmCtx] = None, use_graph: bool = True) -> torch.Tensor:
+        """class_ids int64 [B]; q float32 [L, B, V]; cfg_scales float32 [L] on the host (None: no guidance)."""
+        _require_cuda(class_ids, "class ids")
+        _require_cuda(q, "q")
+        class_ids = class_ids.to(torch.int64).contiguous().view(-1)
+        B = class_ids.shape[0]
+        Ls, V = self.cfg.image_seq_len, self.cfg.codebook_size
+        assert q.shape == (Ls, B, V) and q.dtype == torch.float32 and q.is_contiguous()
+        out = torch.empty(B, Ls, dtype=torch.int64, device=self.device)
+        sc = None
+        if cfg_scales is not None:
+            sc = cfg_scales.detach().to("cpu", torch.float32).contiguous()
+            assert sc.numel() == Ls
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.wmar_rar_generate(
+                self._h, C.byref(wm_ctx) if wm_ctx is not None else None, class_ids.data_ptr(), B,
+                C.cast(sc.data_ptr(), C.POINTER(C.c_float)) if sc is not None else None, 1 if sc is not None else 0,
+                float(temperature), q.data_ptr(), out.data_ptr(), 1 if use_graph else 0, _lib.stream_ptr(self.device)))
+        return out
