@@ -234,6 +234,27 @@ int wmar_vq_decode(wmar_vq* v, const int64_t* codes_dev, int64_t B, float* image
 int wmar_vq_encode(wmar_vq* v, const float* images_dev, int64_t B, int64_t* codes_dev, float* prequant_dev,
                    void* stream);
 
+/* --------------------------------------------------------------- MaskGIT-VQGAN (RAR's tokenizer)
+ * deps/rar/modeling/modules/maskgit_vqgan.py + PretrainedTokenizer (deps/rar/modeling/titok.py:41-89).
+ * Tensors by key name (encoder.*, decoder.*, quantize.embedding.weight).  Images cross this API in the
+ * WRAPPER's convention, [-1, 1] (RarARMMWrapper.codes_to_images / images_to_codes, rar_wrapper.py:108-128). */
+typedef struct wmar_mvq_config {
+    int32_t hidden_channels, num_res_blocks, resolution, num_channels, z_channels, num_embeddings;
+    int32_t n_levels;
+    int32_t channel_mult[8];
+    int32_t max_batch;
+} wmar_mvq_config;
+
+typedef struct wmar_mvq wmar_mvq;
+
+int wmar_mvq_create(const wmar_mvq_config* cfg, const char* const* names, const void* const* tensors_dev,
+                    int32_t n_tensors, void* stream, wmar_mvq** out);
+void wmar_mvq_destroy(wmar_mvq* v);
+int64_t wmar_mvq_device_bytes(const wmar_mvq* v);
+int wmar_mvq_decode(wmar_mvq* v, const int64_t* codes_dev, int64_t B, float* images_dev, void* stream);
+int wmar_mvq_encode(wmar_mvq* v, const float* images_dev, int64_t B, int64_t* codes_dev, float* prequant_dev,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,3 +98,64 @@ def test_generate_without_guidance_vs_oracle(eng, kat, key_factory):
     pv = wm.detect(toks)
     rpv, _, _ = W.detect(key, ref.numpy())
     assert np.allclose(pv.cpu().numpy(), rpv, rtol=1e-9, atol=0, equal_nan=True)
+
+
+MCFG = synth.MaskgitVQConfig(hidden_channels=32, channel_mult=(1, 2, 2), num_res_blocks=1, resolution=32, z_channels=16,
+                             num_embeddings=256)
+
+
+def test_maskgit_tokenizer_golden(rv):
+    from wmar_amd.models.engine import MaskgitVQEngine
+    sd = synth.synth_maskgit_state(MCFG, seed=4)
+    e = MaskgitVQEngine(MCFG, sd, max_batch=4)
+    img = e.decode(torch.from_numpy(rv["mg_codes"]).cuda()).cpu().numpy()
+    np.testing.assert_allclose(img, rv["mg_images"], rtol=0, atol=2e-4)
+    codes, pre = e.encode(torch.from_numpy(rv["mg_images"]).cuda(), return_prequant=True)
+    np.testing.assert_allclose(pre.cpu().numpy(), rv["mg_prequant"], rtol=0, atol=2e-4)
+    assert np.array_equal(codes.cpu().numpy(), rv["mg_codes_roundtrip"])
+
+
+def test_maskgit_mid_config_vs_oracle():
+    from wmar_amd.models.engine import MaskgitVQEngine
+    cfg = synth.MaskgitVQConfig(hidden_channels=32, channel_mult=(1, 1, 2, 4), num_res_blocks=2, resolution=64, z_channels=32,
+                                num_embeddings=512)
+    sd = synth.synth_maskgit_state(cfg, seed=9)
+    e = MaskgitVQEngine(cfg, sd, max_batch=4)
+    rs = np.random.RandomState(1)
+    codes = torch.from_numpy(rs.randint(0, 512, size=(3, cfg.codes_size ** 2)).astype(np.int64))
+    ref = R.maskgit_decode(sd, cfg, codes)
+    img = e.decode(codes.cuda())
+    np.testing.assert_allclose(img.cpu().numpy(), ref.numpy(), rtol=0, atol=5e-4)
+    rz = R.maskgit_prequant(sd, cfg, ref)
+    got, pre = e.encode(ref.cuda(), return_prequant=True)
+    np.testing.assert_allclose(pre.cpu().numpy(), rz.numpy(), rtol=0, atol=5e-4)
+    rc = R.maskgit_argmin(sd["quantize.embedding.weight"], rz).view(3, -1)
+    assert (got.cpu() == rc).float().mean().item() >= 0.99
+
+
+def test_rar_wrapper_end_to_end(kat):
+    """sample -> codes_to_images -> images_to_codes -> detect through the wrapper API."""
+    from wmar_amd.models.rar_wrapper import RarARMMWrapper
+    from wmar_amd.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
+    rcfg = synth.RARConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
+                           image_seq_len=64, codebook_size=256, condition_num_classes=1000)
+    vcfg = synth.MaskgitVQConfig(hidden_channels=32, channel_mult=(1, 2, 2), num_res_blocks=1, resolution=32, z_channels=16,
+                                 num_embeddings=256)
+    rsd = synth.synth_rar_state(rcfg, seed=1, logit_scale=20.0)
+    vsd = synth.synth_maskgit_state(vcfg, seed=1)
+    m = RarARMMWrapper(None, rar_cfg=rcfg, vq_cfg=vcfg, rar_state=rsd, vq_state=vsd, max_batch=4)
+    wm = GentimeWatermark(m.get_vq(), 256, SeedStrategy.LINEAR, SplitStrategy.RANDOM_STRATIFIED, 1, 4.0, 0.25, device="cuda")
+    m.set_watermarker(wm)
+    torch.manual_seed(0)
+    q = m.draw_noise(6)
+    codes = m.sample([1, 2, 3, 4, 5, 6], None, apply_watermark=True, q=q)
+    key = W.KeyParams(wm._alive_host, wm._dead_host, 256, 0.25)
+    ref = R.generate(rsd, rcfg, torch.tensor([1, 2, 3, 4, 5, 6]), 4.0, 0.0, 1.0, key, 4.0,
+                     q_source=lambda n, b, v: q[n].cpu(), draw_drop_mask=False)
+    assert torch.equal(codes.cpu(), ref)
+    imgs = m.codes_to_images(codes)
+    np.testing.assert_allclose(imgs.cpu().numpy(), R.maskgit_decode(vsd, vcfg, ref).numpy(), rtol=0, atol=5e-4)
+    c2 = m.images_to_codes(imgs)
+    assert c2.shape == codes.shape
+    pv = wm.detect(codes)
+    assert float(pv.min()) < 1e-3     # delta=4 watermark is clearly detectable on the generated codes

@@ -19,7 +19,8 @@ SYMBOLS = [
     "wmar_gpt_create", "wmar_gpt_destroy", "wmar_gpt_device_bytes", "wmar_gpt_decode_step", "wmar_gpt_generate",
     "wmar_gpt_set_timing", "wmar_gpt_get_timing", "wmar_gpt_profile_role", "wmar_rar_create", "wmar_rar_destroy",
     "wmar_rar_device_bytes", "wmar_rar_forward_position", "wmar_rar_generate", "wmar_vq_create", "wmar_vq_destroy", "wmar_vq_device_bytes",
-    "wmar_vq_decode", "wmar_vq_encode",
+    "wmar_vq_decode", "wmar_vq_encode", "wmar_mvq_create", "wmar_mvq_destroy", "wmar_mvq_device_bytes", "wmar_mvq_decode",
+    "wmar_mvq_encode",
 ]
 
 WMAR_ESHORT = -3
@@ -58,6 +59,12 @@ class VqConfig(C.Structure):
                 ("embed_dim", C.c_int32), ("n_embed", C.c_int32), ("n_levels", C.c_int32),
                 ("ch_mult", C.c_int32 * 8), ("n_attn_res", C.c_int32), ("attn_resolutions", C.c_int32 * 8),
                 ("max_batch", C.c_int32)]
+
+
+class MvqConfig(C.Structure):
+    _fields_ = [("hidden_channels", C.c_int32), ("num_res_blocks", C.c_int32), ("resolution", C.c_int32),
+                ("num_channels", C.c_int32), ("z_channels", C.c_int32), ("num_embeddings", C.c_int32),
+                ("n_levels", C.c_int32), ("channel_mult", C.c_int32 * 8), ("max_batch", C.c_int32)]
 
 
 class WmarError(RuntimeError):
@@ -121,6 +128,13 @@ def load():
         L.wmar_vq_device_bytes.argtypes = [vp]
         L.wmar_vq_decode.argtypes = [vp, vp, i64, vp, vp]
         L.wmar_vq_encode.argtypes = [vp, vp, i64, vp, vp, vp]
+    L.wmar_mvq_create.argtypes = [C.POINTER(MvqConfig), C.POINTER(C.c_char_p), C.POINTER(vp), i32, vp, C.POINTER(vp)]
+    L.wmar_mvq_destroy.argtypes = [vp]
+    L.wmar_mvq_destroy.restype = None
+    L.wmar_mvq_device_bytes.restype = i64
+    L.wmar_mvq_device_bytes.argtypes = [vp]
+    L.wmar_mvq_decode.argtypes = [vp, vp, i64, vp, vp]
+    L.wmar_mvq_encode.argtypes = [vp, vp, i64, vp, vp, vp]
     _LIB = L
     return L
 

@@ -511,9 +511,27 @@ namespace {
 constexpr int GN_CHUNKS_MAX = 64;
 inline int pad8(int c) { return (c + 7) & ~7; }
 
+struct ArenaRef {   // the engine that owns the allocations
+    std::vector<void*>* allocs;
+    int64_t* bytes;
+    template <typename T>
+    int alloc(T** p, size_t n) {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, (n ? n : 1) * sizeof(T));
+        if (e != hipSuccess) {
+            set_error("hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
+            return WMAR_ENOMEM;
+        }
+        allocs->push_back(q);
+        *bytes += (int64_t)(n * sizeof(T));
+        *p = (T*)q;
+        return WMAR_OK;
+    }
+};
+
 struct Loader {
     std::map<std::string, const void*> m;
-    wmar_vq* v;
+    ArenaRef* v;
     hipStream_t st;
     int rc = WMAR_OK;
     const float* need(const std::string& k) {
@@ -524,9 +542,10 @@ struct Loader {
         }
         return (const float*)it->second;
     }
-    void conv(const std::string& p, int cin, int cout, int ks, ConvW& c) {
+    // has_bias = false: bias-free conv (MaskGIT-VQGAN ResnetBlock / encoder conv_in) -> zero bias
+    void conv(const std::string& p, int cin, int cout, int ks, ConvW& c, bool has_bias = true) {
         const float* W = need(p + ".weight");
-        const float* bsrc = need(p + ".bias");
+        const float* bsrc = has_bias ? need(p + ".bias") : nullptr;
         if (rc) return;
         c.cin = cin; c.cout = cout; c.ks = ks; c.cin_s = pad8(cin); c.cout_s = pad8(cout);
         c.CT = (cout + 31) / 32; c.KBc = c.cin_s / 8;
@@ -534,7 +553,8 @@ struct Loader {
         if ((rc = v->alloc(&c.wp, n))) return;
         hipLaunchKernelGGL(k_pack_conv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, c.wp, cout, cin, ks, c.CT, c.KBc);
         if ((rc = v->alloc(&c.bias, (size_t)c.CT * 32))) return;
-        hipLaunchKernelGGL(k_pad_vec, dim3((c.CT * 32 + 255) / 256), dim3(256), 0, st, bsrc, c.bias, cout, c.CT * 32);
+        if (bsrc) hipLaunchKernelGGL(k_pad_vec, dim3((c.CT * 32 + 255) / 256), dim3(256), 0, st, bsrc, c.bias, cout, c.CT * 32);
+        else if (hipMemsetAsync(c.bias, 0, (size_t)c.CT * 32 * 4, st) != hipSuccess) { set_error("bias memset failed"); rc = WMAR_EHIP; return; }
         rc = launch_status("k_pack_conv");
     }
     void norm(const std::string& p, int C, NormW& n) {
@@ -606,9 +626,9 @@ int run_conv(const ConvW& c, const float* in, float* out, const float* res, int 
     return launch_status("k_conv");
 }
 
-int run_gn(wmar_vq* v, const NormW& n, const float* x, float* y, int B, int HW, int swish, hipStream_t st) {
+int run_gn(double* gn_partial, const NormW& n, const float* x, float* y, int B, int HW, int swish, hipStream_t st) {
     GnArgs a{};
-    a.x = x; a.y = y; a.partial = v->gn_partial; a.gamma = n.g; a.beta = n.b; a.HW = HW; a.C = n.C; a.swish = swish;
+    a.x = x; a.y = y; a.partial = gn_partial; a.gamma = n.g; a.beta = n.b; a.HW = HW; a.C = n.C; a.swish = swish;
     WMAR_REQUIRE(n.C % 32 == 0 && n.C / 4 <= 256, "GroupNorm channel count %d unsupported (multiple of 32, <= 1024)", n.C);
     int nchunk = HW / 256;
     if (nchunk < 1) nchunk = 1;
@@ -625,19 +645,19 @@ int run_gn(wmar_vq* v, const NormW& n, const float* x, float* y, int B, int HW, 
 
 // x (buf X) -> result left in returned buffer index; uses the 4 rotating buffers
 struct Bufs {
-    wmar_vq* v;
+    float** buf;
     int x = 0;          // index of the current activation
-    float* X() { return v->buf[x]; }
-    float* other(int k) { return v->buf[(x + k) & 3]; }
+    float* X() { return buf[x]; }
+    float* other(int k) { return buf[(x + k) & 3]; }
     void advance(int k) { x = (x + k) & 3; }
 };
 
 int run_res(wmar_vq* v, const ResW& r, Bufs& bf, int B, int H, int W, hipStream_t st) {
     int rc;
     float *X = bf.X(), *A = bf.other(1), *T = bf.other(2), *C = bf.other(3);
-    if ((rc = run_gn(v, r.n1, X, A, B, H * W, 1, st))) return rc;
+    if ((rc = run_gn(v->gn_partial, r.n1, X, A, B, H * W, 1, st))) return rc;
     if ((rc = run_conv(r.c1, A, T, nullptr, B, H, W, 1, 0, st))) return rc;
-    if ((rc = run_gn(v, r.n2, T, A, B, H * W, 1, st))) return rc;
+    if ((rc = run_gn(v->gn_partial, r.n2, T, A, B, H * W, 1, st))) return rc;
     const float* shortcut = X;
     if (r.has_nin) {
         if ((rc = run_conv(r.nin, X, C, nullptr, B, H, W, 1, 0, st))) return rc;
@@ -652,7 +672,7 @@ int run_attn(wmar_vq* v, const AttnW& w, Bufs& bf, int B, int H, int W, hipStrea
     int rc;
     const int N = H * W, C = w.n.C;
     float *X = bf.X(), *A = bf.other(1), *T = bf.other(2);
-    if ((rc = run_gn(v, w.n, X, A, B, N, 0, st))) return rc;
+    if ((rc = run_gn(v->gn_partial, w.n, X, A, B, N, 0, st))) return rc;
     if ((rc = run_conv(w.q, A, v->aq, nullptr, B, H, W, 1, 0, st))) return rc;
     if ((rc = run_conv(w.k, A, v->ak, nullptr, B, H, W, 1, 0, st))) return rc;
     if ((rc = run_conv(w.v, A, v->av, nullptr, B, H, W, 1, 0, st))) return rc;
@@ -681,8 +701,9 @@ int wmar_vq_create(const wmar_vq_config* cfg, const char* const* names, const vo
     WMAR_REQUIRE(S >= 8 && S % 8 == 0 && (S << (L - 1)) == cfg->resolution, "latent size %d must be a multiple of 8", S);
     auto* v = new wmar_vq();
     v->cfg = *cfg; v->Bmax = cfg->max_batch; v->S = S;
+    ArenaRef arena{&v->allocs, &v->bytes};
     Loader ld;
-    ld.v = v; ld.st = (hipStream_t)stream;
+    ld.v = &arena; ld.st = (hipStream_t)stream;
     for (int i = 0; i < n_tensors; ++i) ld.m[names[i]] = tensors_dev[i];
     const int ch = cfg->ch, z = cfg->z_channels, E = cfg->embed_dim;
 
@@ -815,7 +836,7 @@ int wmar_vq_decode(wmar_vq* v, const int64_t* codes_dev, int64_t B, float* image
     const wmar_vq_config& c = v->cfg;
     const int L = c.n_levels, S = v->S, E = c.embed_dim;
     int rc;
-    Bufs bf{v};
+    Bufs bf{v->buf};
     // get_codebook_entry (quantize.py:316-331): z_q in NHWC is just the gathered rows
     const long long npix = (long long)B * S * S;
     hipLaunchKernelGGL(k_codebook_gather, dim3((unsigned)((npix * (E / 4) + 255) / 256)), dim3(256), 0, st,
@@ -841,7 +862,7 @@ int wmar_vq_decode(wmar_vq* v, const int64_t* codes_dev, int64_t B, float* image
             H *= 2;
         }
     }
-    if ((rc = run_gn(v, v->d_norm_out, bf.X(), bf.other(1), (int)B, H * H, 1, st))) return rc;
+    if ((rc = run_gn(v->gn_partial, v->d_norm_out, bf.X(), bf.other(1), (int)B, H * H, 1, st))) return rc;
     if ((rc = run_conv(v->d_conv_out, bf.other(1), bf.other(2), nullptr, (int)B, H, H, 1, 0, st))) return rc;
     const int HW = H * H;
     hipLaunchKernelGGL(k_nhwc_to_nchw_clamp, dim3((HW + 255) / 256, (unsigned)B), dim3(256), 0, st, bf.other(2), images_dev,
@@ -857,7 +878,7 @@ int wmar_vq_encode(wmar_vq* v, const float* images_dev, int64_t B, int64_t* code
     const wmar_vq_config& c = v->cfg;
     const int L = c.n_levels, S = v->S, E = c.embed_dim;
     int rc;
-    Bufs bf{v};
+    Bufs bf{v->buf};
     int H = c.resolution;
     hipLaunchKernelGGL(k_nchw_to_nhwc, dim3((H * H + 255) / 256, (unsigned)B), dim3(256), 0, st, images_dev, bf.X(),
                        c.in_channels, H * H, v->e_conv_in.cin_s);
@@ -879,7 +900,7 @@ int wmar_vq_encode(wmar_vq* v, const float* images_dev, int64_t B, int64_t* code
     if ((rc = run_res(v, v->e_mid1, bf, (int)B, H, H, st))) return rc;
     if ((rc = run_attn(v, v->e_midattn, bf, (int)B, H, H, st))) return rc;
     if ((rc = run_res(v, v->e_mid2, bf, (int)B, H, H, st))) return rc;
-    if ((rc = run_gn(v, v->e_norm_out, bf.X(), bf.other(1), (int)B, H * H, 1, st))) return rc;
+    if ((rc = run_gn(v->gn_partial, v->e_norm_out, bf.X(), bf.other(1), (int)B, H * H, 1, st))) return rc;
     if ((rc = run_conv(v->e_conv_out, bf.other(1), bf.other(2), nullptr, (int)B, H, H, 1, 0, st))) return rc;
     if ((rc = run_conv(v->quant, bf.other(2), bf.other(3), nullptr, (int)B, H, H, 1, 0, st))) return rc;
     float* zq = bf.other(3);   // [B*S*S][E] (E is a multiple of 8: no channel padding)
@@ -890,6 +911,280 @@ int wmar_vq_encode(wmar_vq* v, const float* images_dev, int64_t B, int64_t* code
     a.z = zq; a.ep = v->emb_p; a.enorm = v->enorm; a.znorm = v->znorm; a.codes = (long long*)codes_dev; a.P = P;
     a.E = E; a.n_embed = c.n_embed;
     const size_t lds = (size_t)64 * (E + 4) * sizeof(float);
+    WMAR_HIP_CHECK(hipFuncSetAttribute((const void*)k_vq_argmin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_vq_argmin, dim3((unsigned)((P + 63) / 64)), dim3(256), lds, st, a);
+    return launch_status("k_vq_argmin");
+}
+
+}  // extern "C"
+
+// ============================================================================ MaskGIT-VQGAN
+// RAR's tokenizer (deps/rar/modeling/modules/maskgit_vqgan.py, deps/rar/modeling/titok.py:41-89):
+// the same conv / GroupNorm / quantizer kernels with a different plan -- no attention, bias-free
+// 3x3 convs inside the ResnetBlocks, the 1x1 shortcut applied to the block OUTPUT, average-pool
+// downsampling, images in [0, 1] on the tokenizer side and [-1, 1] on the wrapper side.
+namespace wmar {
+
+// 2x2 average pool, NHWC (DownsamplingBlock.forward, maskgit_vqgan.py:118-119)
+__global__ void k_avgpool2(const float* __restrict__ in, float* __restrict__ out, int Ho, int Wo, int C) {
+    const long long q4 = C >> 2;
+    const long long total = (long long)Ho * Wo * q4;
+    const long long b = blockIdx.y;
+    const float* ib = in + b * (long long)(2 * Ho) * (2 * Wo) * C;
+    float* ob = out + b * (long long)Ho * Wo * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % q4) * 4;
+        const long long pix = e / q4;
+        const int ox = (int)(pix % Wo), oy = (int)(pix / Wo);
+        const float* p = ib + ((long long)(2 * oy) * (2 * Wo) + 2 * ox) * C + c;
+        const float4 a = *(const float4*)p, b2 = *(const float4*)(p + C);
+        const float4 c2 = *(const float4*)(p + (long long)2 * Wo * C), d = *(const float4*)(p + (long long)2 * Wo * C + C);
+        // F.avg_pool2d: sum of the window (row-major order) divided by the window size
+        *(float4*)(ob + pix * C + c) = make_float4((a.x + b2.x + c2.x + d.x) / 4.0f, (a.y + b2.y + c2.y + d.y) / 4.0f,
+                                                   (a.z + b2.z + c2.z + d.z) / 4.0f, (a.w + b2.w + c2.w + d.w) / 4.0f);
+    }
+}
+
+// NCHW [-1,1] -> NHWC [0,1]:  (x + 1) / 2   (rar_wrapper.py:124)
+__global__ void k_nchw_to_nhwc01(const float* __restrict__ src, float* __restrict__ dst, int C, int HW, int Cs) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long b = blockIdx.y;
+    if (idx >= HW) return;
+    for (int c = 0; c < Cs; ++c)
+        dst[((long long)b * HW + idx) * Cs + c] = c < C ? (src[((long long)b * C + c) * HW + idx] + 1.0f) / 2.0f : 0.f;
+}
+
+// NHWC -> NCHW: clamp(x, 0, 1) (titok.py:84) then clamp(x*2 - 1, -1, 1) (rar_wrapper.py:113-114)
+__global__ void k_nhwc_to_nchw_01(const float* __restrict__ src, float* __restrict__ dst, int C, int HW, int Cs) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long b = blockIdx.y;
+    if (idx >= HW) return;
+    for (int c = 0; c < C; ++c) {
+        float v = src[((long long)b * HW + idx) * Cs + c];
+        v = fminf(fmaxf(v, 0.0f), 1.0f);
+        v = v * 2.0f - 1.0f;
+        dst[((long long)b * C + c) * HW + idx] = fminf(fmaxf(v, -1.0f), 1.0f);
+    }
+}
+
+}  // namespace wmar
+
+struct wmar_mvq {
+    wmar_mvq_config cfg{};
+    std::vector<void*> allocs;
+    int64_t bytes = 0;
+    int Bmax = 0, S = 0;
+    ConvW d_conv_in, d_conv_out, e_conv_in, e_conv_out;
+    std::vector<ResW> d_mid, e_mid;
+    std::vector<std::vector<ResW>> d_up, e_down;
+    std::vector<ConvW> d_upconv;
+    NormW d_norm_out, e_norm_out;
+    float* emb = nullptr; float4* emb_p = nullptr; float* enorm = nullptr;
+    float* buf[4] = {nullptr, nullptr, nullptr, nullptr};
+    double* gn_partial = nullptr;
+    float* znorm = nullptr;
+    ~wmar_mvq() { for (void* p : allocs) (void)hipFree(p); }
+};
+
+namespace {
+
+void mres_load(Loader& ld, const std::string& p, int cin, int cout, ResW& r) {
+    ld.norm(p + "norm1", cin, r.n1);
+    ld.conv(p + "conv1", cin, cout, 3, r.c1, false);
+    ld.norm(p + "norm2", cout, r.n2);
+    ld.conv(p + "conv2", cout, cout, 3, r.c2, false);
+    r.has_nin = cin != cout;
+    if (r.has_nin) ld.conv(p + "nin_shortcut", cout, cout, 1, r.nin, false);
+}
+
+// ResnetBlock.forward (maskgit_vqgan.py:69-87): out = h + (cin != cout ? nin(h) : x),  h = conv2(...)
+int run_mres(wmar_mvq* v, const ResW& r, Bufs& bf, int B, int H, int W, hipStream_t st) {
+    int rc;
+    float *X = bf.X(), *A = bf.other(1), *T = bf.other(2), *C = bf.other(3);
+    if ((rc = run_gn(v->gn_partial, r.n1, X, A, B, H * W, 1, st))) return rc;
+    if ((rc = run_conv(r.c1, A, T, nullptr, B, H, W, 1, 0, st))) return rc;
+    if ((rc = run_gn(v->gn_partial, r.n2, T, A, B, H * W, 1, st))) return rc;
+    if (r.has_nin) {
+        if ((rc = run_conv(r.c2, A, T, nullptr, B, H, W, 1, 0, st))) return rc;
+        if ((rc = run_conv(r.nin, T, C, T, B, H, W, 1, 0, st))) return rc;      // nin(h) + h
+        bf.advance(3);
+    } else {
+        if ((rc = run_conv(r.c2, A, T, X, B, H, W, 1, 0, st))) return rc;        // h + x
+        bf.advance(2);
+    }
+    return WMAR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wmar_mvq_create(const wmar_mvq_config* cfg, const char* const* names, const void* const* tensors_dev,
+                    int32_t n_tensors, void* stream, wmar_mvq** out) {
+    WMAR_REQUIRE(cfg && names && tensors_dev && out, "mvq_create: null argument");
+    WMAR_REQUIRE(cfg->n_levels >= 1 && cfg->n_levels <= 8 && cfg->max_batch >= 1, "mvq_create: bad config");
+    WMAR_REQUIRE(cfg->z_channels % 8 == 0 && cfg->num_embeddings % 32 == 0 && cfg->hidden_channels % 32 == 0,
+                 "z_channels %% 8, num_embeddings %% 32 and hidden_channels %% 32 must be 0");
+    const int R = cfg->n_levels, hc = cfg->hidden_channels, z = cfg->z_channels;
+    const int S = cfg->resolution >> (R - 1);
+    WMAR_REQUIRE(S >= 8 && S % 8 == 0 && (S << (R - 1)) == cfg->resolution, "latent size %d must be a multiple of 8", S);
+    auto* v = new wmar_mvq();
+    v->cfg = *cfg; v->Bmax = cfg->max_batch; v->S = S;
+    ArenaRef arena{&v->allocs, &v->bytes};
+    Loader ld;
+    ld.v = &arena; ld.st = (hipStream_t)stream;
+    for (int i = 0; i < n_tensors; ++i) ld.m[names[i]] = tensors_dev[i];
+    const int mid = hc * cfg->channel_mult[R - 1];
+    // decoder (maskgit_vqgan.py:197-245)
+    ld.conv("decoder.conv_in", z, mid, 3, v->d_conv_in);
+    v->d_mid.resize(cfg->num_res_blocks);
+    for (int b = 0; b < cfg->num_res_blocks; ++b) mres_load(ld, "decoder.mid." + std::to_string(b) + ".", mid, mid, v->d_mid[b]);
+    v->d_up.resize(R); v->d_upconv.resize(R);
+    for (int lvl = 0; lvl < R; ++lvl) {
+        int bi = lvl == R - 1 ? hc * cfg->channel_mult[R - 1] : hc * cfg->channel_mult[lvl + 1];
+        const int bo = hc * cfg->channel_mult[lvl];
+        v->d_up[lvl].resize(cfg->num_res_blocks);
+        for (int b = 0; b < cfg->num_res_blocks; ++b) {
+            mres_load(ld, "decoder.up." + std::to_string(lvl) + ".block." + std::to_string(b) + ".", bi, bo, v->d_up[lvl][b]);
+            bi = bo;
+        }
+        if (lvl != 0) ld.conv("decoder.up." + std::to_string(lvl) + ".upsample_conv", bo, bo, 3, v->d_upconv[lvl]);
+    }
+    ld.norm("decoder.norm_out", hc * cfg->channel_mult[0], v->d_norm_out);
+    ld.conv("decoder.conv_out", hc * cfg->channel_mult[0], cfg->num_channels, 3, v->d_conv_out);
+    // encoder (maskgit_vqgan.py:157-194)
+    ld.conv("encoder.conv_in", cfg->num_channels, hc, 3, v->e_conv_in, false);
+    v->e_down.resize(R);
+    for (int lvl = 0; lvl < R; ++lvl) {
+        int bi = hc * (lvl == 0 ? 1 : cfg->channel_mult[lvl - 1]);
+        const int bo = hc * cfg->channel_mult[lvl];
+        v->e_down[lvl].resize(cfg->num_res_blocks);
+        for (int b = 0; b < cfg->num_res_blocks; ++b) {
+            mres_load(ld, "encoder.down." + std::to_string(lvl) + ".block." + std::to_string(b) + ".", bi, bo, v->e_down[lvl][b]);
+            bi = bo;
+        }
+    }
+    v->e_mid.resize(cfg->num_res_blocks);
+    for (int b = 0; b < cfg->num_res_blocks; ++b) mres_load(ld, "encoder.mid." + std::to_string(b) + ".", mid, mid, v->e_mid[b]);
+    ld.norm("encoder.norm_out", mid, v->e_norm_out);
+    ld.conv("encoder.conv_out", mid, z, 1, v->e_conv_out);
+    const float* emb = ld.need("quantize.embedding.weight");
+    int rc = ld.rc;
+    hipStream_t st = (hipStream_t)stream;
+#define TRY(x) do { if (rc == WMAR_OK) rc = (x); } while (0)
+    TRY(arena.alloc(&v->emb, (size_t)cfg->num_embeddings * z));
+    if (rc == WMAR_OK && hipMemcpyAsync(v->emb, emb, (size_t)cfg->num_embeddings * z * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        set_error("embedding copy failed"); rc = WMAR_EHIP;
+    }
+    TRY(arena.alloc(&v->emb_p, (size_t)cfg->num_embeddings * z / 4));
+    TRY(arena.alloc(&v->enorm, (size_t)cfg->num_embeddings));
+    if (rc == WMAR_OK) {
+        size_t n = (size_t)(cfg->num_embeddings / 32) * (z / 8) * 64;
+        hipLaunchKernelGGL(k_pack_conv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, emb, v->emb_p, cfg->num_embeddings, z, 1,
+                           cfg->num_embeddings / 32, z / 8);
+        hipLaunchKernelGGL(k_row_sqnorm, dim3(cfg->num_embeddings), dim3(64), 0, st, v->emb, v->enorm, z);
+        rc = launch_status("codebook pack");
+    }
+    size_t maxel = 0;
+    {
+        int r = cfg->resolution;
+        for (int lvl = 0; lvl < R; ++lvl) {
+            int cmax = hc * cfg->channel_mult[lvl];
+            if (lvl > 0 && hc * cfg->channel_mult[lvl - 1] > cmax) cmax = hc * cfg->channel_mult[lvl - 1];
+            if (lvl + 1 < R && hc * cfg->channel_mult[lvl + 1] > cmax) cmax = hc * cfg->channel_mult[lvl + 1];
+            if (z > cmax && lvl == R - 1) cmax = z;
+            size_t el = (size_t)r * r * pad8(cmax);
+            if (el > maxel) maxel = el;
+            r /= 2;
+        }
+    }
+    for (int i = 0; i < 4; ++i) TRY(arena.alloc(&v->buf[i], maxel * v->Bmax));
+    TRY(arena.alloc(&v->gn_partial, (size_t)v->Bmax * GN_CHUNKS_MAX * 32 * 2));
+    TRY(arena.alloc(&v->znorm, (size_t)v->Bmax * S * S));
+    if (rc == WMAR_OK && hipStreamSynchronize(st) != hipSuccess) { set_error("mvq_create: sync failed"); rc = WMAR_EHIP; }
+#undef TRY
+    if (rc != WMAR_OK) { delete v; return rc; }
+    *out = v;
+    return WMAR_OK;
+}
+
+void wmar_mvq_destroy(wmar_mvq* v) { delete v; }
+int64_t wmar_mvq_device_bytes(const wmar_mvq* v) { return v ? v->bytes : 0; }
+
+int wmar_mvq_decode(wmar_mvq* v, const int64_t* codes_dev, int64_t B, float* images_dev, void* stream) {
+    WMAR_REQUIRE(v && codes_dev && images_dev, "mvq_decode: null argument");
+    WMAR_REQUIRE(B >= 1 && B <= v->Bmax, "mvq_decode: batch %lld outside 1..%d", (long long)B, v->Bmax);
+    hipStream_t st = (hipStream_t)stream;
+    const wmar_mvq_config& c = v->cfg;
+    const int R = c.n_levels, S = v->S, z = c.z_channels;
+    int rc;
+    Bufs bf{v->buf};
+    const long long npix = (long long)B * S * S;
+    hipLaunchKernelGGL(k_codebook_gather, dim3((unsigned)((npix * (z / 4) + 255) / 256)), dim3(256), 0, st,
+                       (const long long*)codes_dev, v->emb, bf.X(), npix, z, c.num_embeddings);
+    if ((rc = launch_status("k_codebook_gather"))) return rc;
+    if ((rc = run_conv(v->d_conv_in, bf.X(), bf.other(1), nullptr, (int)B, S, S, 1, 0, st))) return rc;
+    bf.advance(1);
+    int H = S;
+    for (auto& r : v->d_mid)
+        if ((rc = run_mres(v, r, bf, (int)B, H, H, st))) return rc;
+    for (int lvl = R - 1; lvl >= 0; --lvl) {
+        for (auto& r : v->d_up[lvl])
+            if ((rc = run_mres(v, r, bf, (int)B, H, H, st))) return rc;
+        if (lvl != 0) {
+            if ((rc = run_conv(v->d_upconv[lvl], bf.X(), bf.other(1), nullptr, (int)B, H, H, 1, 1, st))) return rc;
+            bf.advance(1);
+            H *= 2;
+        }
+    }
+    if ((rc = run_gn(v->gn_partial, v->d_norm_out, bf.X(), bf.other(1), (int)B, H * H, 1, st))) return rc;
+    if ((rc = run_conv(v->d_conv_out, bf.other(1), bf.other(2), nullptr, (int)B, H, H, 1, 0, st))) return rc;
+    const int HW = H * H;
+    hipLaunchKernelGGL(k_nhwc_to_nchw_01, dim3((HW + 255) / 256, (unsigned)B), dim3(256), 0, st, bf.other(2), images_dev,
+                       c.num_channels, HW, v->d_conv_out.cout_s);
+    return launch_status("k_nhwc_to_nchw_01");
+}
+
+int wmar_mvq_encode(wmar_mvq* v, const float* images_dev, int64_t B, int64_t* codes_dev, float* prequant_dev, void* stream) {
+    WMAR_REQUIRE(v && images_dev && codes_dev, "mvq_encode: null argument");
+    WMAR_REQUIRE(B >= 1 && B <= v->Bmax, "mvq_encode: batch %lld outside 1..%d", (long long)B, v->Bmax);
+    hipStream_t st = (hipStream_t)stream;
+    const wmar_mvq_config& c = v->cfg;
+    const int R = c.n_levels, S = v->S, z = c.z_channels;
+    int rc;
+    Bufs bf{v->buf};
+    int H = c.resolution;
+    hipLaunchKernelGGL(k_nchw_to_nhwc01, dim3((H * H + 255) / 256, (unsigned)B), dim3(256), 0, st, images_dev, bf.X(),
+                       c.num_channels, H * H, v->e_conv_in.cin_s);
+    if ((rc = launch_status("k_nchw_to_nhwc01"))) return rc;
+    if ((rc = run_conv(v->e_conv_in, bf.X(), bf.other(1), nullptr, (int)B, H, H, 1, 0, st))) return rc;
+    bf.advance(1);
+    for (int lvl = 0; lvl < R; ++lvl) {
+        for (auto& r : v->e_down[lvl])
+            if ((rc = run_mres(v, r, bf, (int)B, H, H, st))) return rc;
+        if (lvl != R - 1) {
+            const int C = c.hidden_channels * c.channel_mult[lvl];
+            const long long total = (long long)(H / 2) * (H / 2) * (C / 4);
+            int gx = (int)((total + 255) / 256);
+            if (gx > 8192) gx = 8192;
+            hipLaunchKernelGGL(k_avgpool2, dim3(gx, (unsigned)B), dim3(256), 0, st, bf.X(), bf.other(1), H / 2, H / 2, C);
+            if ((rc = launch_status("k_avgpool2"))) return rc;
+            bf.advance(1);
+            H /= 2;
+        }
+    }
+    for (auto& r : v->e_mid)
+        if ((rc = run_mres(v, r, bf, (int)B, H, H, st))) return rc;
+    if ((rc = run_gn(v->gn_partial, v->e_norm_out, bf.X(), bf.other(1), (int)B, H * H, 1, st))) return rc;
+    if ((rc = run_conv(v->e_conv_out, bf.other(1), bf.other(2), nullptr, (int)B, H, H, 1, 0, st))) return rc;
+    float* zq = bf.other(2);
+    const long long P = (long long)B * S * S;
+    if (prequant_dev) WMAR_HIP_CHECK(hipMemcpyAsync(prequant_dev, zq, (size_t)P * z * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_row_sqnorm, dim3((unsigned)P), dim3(64), 0, st, zq, v->znorm, z);
+    VqArgs a{};
+    a.z = zq; a.ep = v->emb_p; a.enorm = v->enorm; a.znorm = v->znorm; a.codes = (long long*)codes_dev; a.P = P;
+    a.E = z; a.n_embed = c.num_embeddings;
+    const size_t lds = (size_t)64 * (z + 4) * sizeof(float);
     WMAR_HIP_CHECK(hipFuncSetAttribute((const void*)k_vq_argmin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_vq_argmin, dim3((unsigned)((P + 63) / 64)), dim3(256), lds, st, a);
     return launch_status("k_vq_argmin");

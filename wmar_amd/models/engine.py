@@ -232,3 +232,67 @@ class RAREngine:
                 C.cast(sc.data_ptr(), C.POINTER(C.c_float)) if sc is not None else None, 1 if sc is not None else 0,
                 float(temperature), q.data_ptr(), out.data_ptr(), 1 if use_graph else 0, _lib.stream_ptr(self.device)))
         return out
+
+
+class MaskgitVQEngine:
+    """MaskGIT-VQGAN tokenizer of RAR; replaces PretrainedTokenizer.encode / decode_tokens
+    (deps/rar/modeling/titok.py:75-89) incl. the wrapper's [-1,1] <-> [0,1] rescaling."""
+
+    def __init__(self, cfg, state: Dict[str, torch.Tensor], max_batch: int = 64, device="cuda"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.max_batch = int(max_batch)
+        L = _lib.load()
+        tensors = {k: v.detach().to(device=self.device, dtype=torch.float32).contiguous() for k, v in state.items()
+                   if k.startswith(("encoder.", "decoder.", "quantize."))}
+        names, ptrs, n = _lib.tensor_table(tensors)
+        c = _lib.MvqConfig()
+        c.hidden_channels, c.num_res_blocks, c.resolution = cfg.hidden_channels, cfg.num_res_blocks, cfg.resolution
+        c.num_channels, c.z_channels, c.num_embeddings = cfg.num_channels, cfg.z_channels, cfg.num_embeddings
+        c.n_levels = len(cfg.channel_mult)
+        for i, m in enumerate(cfg.channel_mult):
+            c.channel_mult[i] = m
+        c.max_batch = self.max_batch
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(L.wmar_mvq_create(C.byref(c), names, ptrs, n, _lib.stream_ptr(self.device), C.byref(h)))
+        self._h = h
+        self._L = L
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.wmar_mvq_destroy(h)
+            self._h = None
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self._L.wmar_mvq_device_bytes(self._h))
+
+    def decode(self, codes: torch.Tensor) -> torch.Tensor:
+        _require_cuda(codes, "codes")
+        codes = codes.to(torch.int64).contiguous()
+        B = codes.shape[0]
+        R = self.cfg.resolution
+        out = torch.empty(B, self.cfg.num_channels, R, R, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            for b0 in range(0, B, self.max_batch):
+                b1 = min(B, b0 + self.max_batch)
+                _lib.check(self._L.wmar_mvq_decode(self._h, codes[b0:b1].data_ptr(), b1 - b0, out[b0:b1].data_ptr(),
+                                                   _lib.stream_ptr(self.device)))
+        return out
+
+    def encode(self, images: torch.Tensor, return_prequant: bool = False):
+        _require_cuda(images, "images")
+        images = images.to(torch.float32).contiguous()
+        B = images.shape[0]
+        S = self.cfg.codes_size
+        codes = torch.empty(B, S * S, dtype=torch.int64, device=self.device)
+        pre = torch.empty(B * S * S, self.cfg.z_channels, dtype=torch.float32, device=self.device) if return_prequant else None
+        with torch.cuda.device(self.device):
+            for b0 in range(0, B, self.max_batch):
+                b1 = min(B, b0 + self.max_batch)
+                _lib.check(self._L.wmar_mvq_encode(
+                    self._h, images[b0:b1].data_ptr(), b1 - b0, codes[b0:b1].data_ptr(),
+                    pre[b0 * S * S:b1 * S * S].data_ptr() if pre is not None else None, _lib.stream_ptr(self.device)))
+        return (codes, pre) if return_prequant else codes
