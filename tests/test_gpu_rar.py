@@ -69,6 +69,28 @@ def test_forward_odd_head_dims_vs_oracle(hd_cfg):
         tok = torch.from_numpy(rs.randint(0, 256, size=M).astype(np.int64))
 
 
+def test_forward_128_rows_wide_mlp_vs_oracle():
+    """M = 128 rows (batch 64 under guidance) with an MLP wide enough that the GELU GEMM runs four row tiles per workgroup."""
+    from wmar_amd.models.engine import RAREngine
+    cfg = synth.RARConfig(hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=4224,
+                          image_seq_len=16, codebook_size=256, condition_num_classes=10)
+    sd = synth.synth_rar_state(cfg, seed=11, logit_scale=20.0)
+    e = RAREngine(cfg, sd, max_batch=64)
+    M = 128
+    rs = np.random.RandomState(3)
+    cond = torch.from_numpy(rs.randint(257, 267, size=M).astype(np.int64))
+    ce = sd["embeddings.weight"][cond]
+    cls = sd["cls_token"][0, 0].expand(M, -1)
+    _, kc, vc = R.rar_position(sd, cfg, cls, ce, 0, None, None)
+    e.forward_position(torch.full((M,), -1, dtype=torch.int64).cuda(), cond.cuda(), 0)
+    tok = cond
+    for p in range(1, 4):
+        ref, kc, vc = R.rar_position(sd, cfg, sd["embeddings.weight"][tok], ce, p, kc, vc)
+        lg = e.forward_position(tok.cuda(), cond.cuda(), p).cpu().numpy()
+        np.testing.assert_allclose(lg, ref.numpy(), rtol=0, atol=5e-4)
+        tok = torch.from_numpy(rs.randint(0, 256, size=M).astype(np.int64))
+
+
 @pytest.mark.parametrize("graph", [True, False])
 @pytest.mark.parametrize("tag,gs,gp,T,use_wm", [("wm", 4.0, 0.0, 1.0, True), ("nowm", 4.0, 0.0, 1.0, False),
                                                 ("pow", 3.0, 1.5, 0.9, True)])

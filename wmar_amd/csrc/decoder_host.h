@@ -67,6 +67,12 @@ inline int pick_split(int tiles, int KB, int NW) {
 template <int EPI, bool LN>
 int gemm_dispatch(GemmArgs a, bool allow_split, hipStream_t st) {
     constexpr int NW = 4;
+    // four row tiles per workgroup once two would need more than one workgroup per CU: a second
+    // workgroup on a CU shares its MFMA pipes, so the launch takes as long as the busiest CU
+    if (a.MT % 4 == 0 && a.NT * (a.MT / 2) > 256) {
+        a.S = allow_split ? pick_split(a.NT * (a.MT / 4), a.KB, NW) : 1;
+        return launch_gemm<4, NW, EPI, LN, 0, 2>(a, st);
+    }
     if (a.MT % 2 == 0) {
         a.S = allow_split ? pick_split(a.NT * (a.MT / 2), a.KB, NW) : 1;
         return launch_gemm<2, NW, EPI, LN>(a, st);

@@ -67,6 +67,8 @@ struct ResidArgs {
     const float* bias;         // [K]
     const float* gate;         // nullable: row-major [M][gate_stride] per-row, per-channel gate (RAR adaLN)
     long long gate_stride;
+    const float* gate_u;       // nullable: rows >= gate_split share row *pos_dev of this [T][gate_stride] table
+    int gate_split;
     double* stats;             // [n_chunks][Mpad][2]
     int KB, MT, n_chunks;
     // embed
@@ -97,6 +99,10 @@ __global__ __launch_bounds__(256) void k_resid_stats(ResidArgs a) {
         erow = a.tok_emb + tk * a.K;
         prow = a.pos_emb + (long long)pos * a.K;
     }
+    const float* grow = nullptr;
+    if (!EMBED && a.gate)
+        grow = (a.gate_u && m >= a.gate_split) ? a.gate_u + (long long)(*a.pos_dev) * a.gate_stride
+                                               : a.gate + (long long)m * a.gate_stride;
     float4 v[KPW], bb[KPW], sl[KPW][S > 0 ? S : 1];
     int kbs[KPW];
 #pragma unroll
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(256) void k_resid_stats(ResidArgs a) {
                 acc.x += sl[i][sidx].x; acc.y += sl[i][sidx].y; acc.z += sl[i][sidx].z; acc.w += sl[i][sidx].w;
             }
             float4 gg = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (a.gate) gg = *(const float4*)(a.gate + (long long)m * a.gate_stride + kbs[i] * 8 + 4 * half);
+            if (a.gate) gg = *(const float4*)(grow + kbs[i] * 8 + 4 * half);
             r = make_float4(v[i].x + gg.x * (bb[i].x + acc.x), v[i].y + gg.y * (bb[i].y + acc.y),
                             v[i].z + gg.z * (bb[i].z + acc.z), v[i].w + gg.w * (bb[i].w + acc.w));
         }

@@ -38,6 +38,7 @@ struct RarEmbedArgs {
     long long ids_stride;
     const int* pos_dev;
     int KB, MT, n_chunks, M, Bhalf, K;
+    int MTsc;                // row tiles of sc (rows past MTsc*32 take their modulation from the shared table)
 };
 
 static __global__ __launch_bounds__(256) void k_rar_embed(RarEmbedArgs a) {
@@ -80,7 +81,7 @@ static __global__ __launch_bounds__(256) void k_rar_embed(RarEmbedArgs a) {
         float cv[4] = {ce.x + te.x, ce.y + te.y, ce.z + te.z, ce.w + te.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) cv[j] = cv[j] / (1.0f + expf(-cv[j]));   // SiLU
-        a.sc[idx] = make_float4(cv[0], cv[1], cv[2], cv[3]);
+        if (mt < a.MTsc) a.sc[((long long)kb * a.MTsc + mt) * 64 + lane] = make_float4(cv[0], cv[1], cv[2], cv[3]);
     }
     s += __shfl_xor(s, 32);
     ss += __shfl_xor(ss, 32);
@@ -100,6 +101,8 @@ struct ModArgs {
     const float4* x; float4* h; const double* stats;
     const float* gamma; const float* beta;
     const float* shift; const float* scale; long long mod_stride;
+    const float* shift_u; const float* scale_u;   // nullable: rows >= split share row *pos_dev of the [T][mod_stride] table
+    const int* pos_dev; int split;
     int KB, MT, n_chunks, K;
 };
 
@@ -125,6 +128,10 @@ static __global__ __launch_bounds__(256) void k_modulate(ModArgs a) {
         mu = (float)mean;
         rstd = rsqrtf((float)(sq * invK - mean * mean) + 1e-6f);
     }
+    const bool shared = a.shift_u && m >= a.split;
+    const long long mrow = shared ? (long long)(*a.pos_dev) * a.mod_stride : (long long)m * a.mod_stride;
+    const float* scale = (shared ? a.scale_u : a.scale) + mrow;
+    const float* shift = (shared ? a.shift_u : a.shift) + mrow;
     for (int kb = kb0 + w; kb < kb1; kb += 4) {
         const int k = kb * 8 + 4 * half;
         const long long idx = ((long long)kb * a.MT + mt) * 64 + lane;
@@ -134,11 +141,27 @@ static __global__ __launch_bounds__(256) void k_modulate(ModArgs a) {
             const float4 g = *(const float4*)(a.gamma + k), bt = *(const float4*)(a.beta + k);
             r[0] = r[0] * g.x + bt.x; r[1] = r[1] * g.y + bt.y; r[2] = r[2] * g.z + bt.z; r[3] = r[3] * g.w + bt.w;
         }
-        const float4 sc = *(const float4*)(a.scale + (long long)m * a.mod_stride + k);
-        const float4 sh = *(const float4*)(a.shift + (long long)m * a.mod_stride + k);
+        const float4 sc = *(const float4*)(scale + k);
+        const float4 sh = *(const float4*)(shift + k);
         a.h[idx] = make_float4(r[0] * (1.0f + sc.x) + sh.x, r[1] * (1.0f + sc.y) + sh.y, r[2] * (1.0f + sc.z) + sh.z,
                                r[3] * (1.0f + sc.w) + sh.w);
     }
+}
+
+// SiLU(emb[cond] + timesteps[p]) for p = 0..T-1 in packed layout: the adaLN input of a row whose
+// condition never changes (the unconditional half under guidance).
+static __global__ void k_rar_cond_rows(float4* sc, const float* emb, const float* tstep, long long cond, int T, int MT, int K) {
+    const int kb = blockIdx.x / MT, mt = blockIdx.x % MT;
+    const int lane = threadIdx.x, p = mt * 32 + (lane & 31), half = lane >> 5;
+    const int k = kb * 8 + 4 * half;
+    float cv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p < T) {
+        const float4 ce = *(const float4*)(emb + cond * K + k), te = *(const float4*)(tstep + (long long)p * K + k);
+        cv[0] = ce.x + te.x; cv[1] = ce.y + te.y; cv[2] = ce.z + te.z; cv[3] = ce.w + te.w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cv[j] = cv[j] / (1.0f + expf(-cv[j]));
+    }
+    sc[((long long)kb * MT + mt) * 64 + lane] = make_float4(cv[0], cv[1], cv[2], cv[3]);
 }
 
 // tok_out[b] replicated to the unconditional half happens implicitly: ids are shared by b % B.
@@ -165,6 +188,8 @@ struct wmar_rar {
     // workspaces
     float4 *x = nullptr, *h = nullptr, *y = nullptr, *hbuf = nullptr, *sc = nullptr, *slabs = nullptr, *qkv_slabs = nullptr;
     float* mod = nullptr;
+    float* mod_u = nullptr;   // [T][Ntot] modulations of the unconditional row at every position (built on first guided generate)
+    bool mod_u_ready = false;
     double* stats = nullptr;
     float *kcache = nullptr, *vcache = nullptr, *logits = nullptr, *scratch = nullptr, *cfg_scale = nullptr;
     long long *ids = nullptr, *cond_ids = nullptr;
@@ -201,9 +226,13 @@ struct RarPlan {
     long long act;
     int S_proj, S_fc2;
     const long long* tok;   // explicit tokens (forward_position) or null
+    bool shared_u;          // rows [Bhalf, M) all carry the "none" condition: their adaLN modulation comes from g->mod_u
+    int MTc;                // row tiles of the adaLN GEMM
 
-    RarPlan(wmar_rar* g_, int M_, int Bhalf_, const long long* tok_, hipStream_t st_) : g(g_), M(M_), Bhalf(Bhalf_), st(st_), tok(tok_) {
+    RarPlan(wmar_rar* g_, int M_, int Bhalf_, const long long* tok_, hipStream_t st_, bool shared_u_ = false)
+        : g(g_), M(M_), Bhalf(Bhalf_), st(st_), tok(tok_), shared_u(shared_u_) {
         MT = mt_for(M); D = g->D; KBD = D / 8; KBF = g->F / 8; nch = stat_chunks(KBD);
+        MTc = shared_u ? mt_for(Bhalf) : MT;
         act = (long long)KBD * MT * 64;
         const int tiles = MT % 2 == 0 ? (D / 32) * (MT / 2) : (D / 32) * MT;
         S_proj = pick_split(tiles, KBD, 4);
@@ -219,7 +248,7 @@ struct RarPlan {
         RarEmbedArgs e{};
         e.x = g->x; e.sc = g->sc; e.stats = g->stats; e.emb = g->emb; e.cls = g->cls; e.pos = g->pos; e.tape = g->tape;
         e.tstep = g->tstep; e.tok = tok; e.cond = g->cond_ids; e.ids = g->ids; e.ids_stride = g->cfg.image_seq_len;
-        e.pos_dev = g->ctr; e.KB = KBD; e.MT = MT; e.n_chunks = nch; e.M = M; e.Bhalf = Bhalf; e.K = D;
+        e.pos_dev = g->ctr; e.KB = KBD; e.MT = MT; e.n_chunks = nch; e.M = M; e.Bhalf = Bhalf; e.K = D; e.MTsc = MTc;
         hipLaunchKernelGGL(k_rar_embed, dim3(nch * MT), dim3(256), 0, st, e);
         return launch_status("k_rar_embed");
     }
@@ -228,12 +257,15 @@ struct RarPlan {
         GemmArgs a = base();
         a.Wp = g->wada; a.Xp = g->sc; a.KB = KBD; a.NT = (int)(g->Ntot / 32); a.bias = g->bada;
         a.logits = g->mod; a.V = (int)g->Ntot;
+        if (shared_u) { a.MT = MTc; a.B = Bhalf; }
         return gemm_dispatch<EPI_LOGITS, false>(a, false, st);
     }
     int modulate(const float* gamma, const float* beta, long long off_shift, long long off_scale) {
         ModArgs m{};
         m.x = g->x; m.h = g->h; m.stats = g->stats; m.gamma = gamma; m.beta = beta;
         m.shift = g->mod + off_shift; m.scale = g->mod + off_scale; m.mod_stride = g->Ntot;
+        if (shared_u) { m.shift_u = g->mod_u + off_shift; m.scale_u = g->mod_u + off_scale; m.split = Bhalf; }
+        m.pos_dev = g->ctr;
         m.KB = KBD; m.MT = MT; m.n_chunks = nch; m.K = D;
         hipLaunchKernelGGL(k_modulate, dim3(nch * MT), dim3(256), 0, st, m);
         return launch_status("k_modulate");
@@ -242,7 +274,8 @@ struct RarPlan {
         ResidArgs r{};
         r.x = g->x; r.stats = g->stats; r.KB = KBD; r.MT = MT; r.n_chunks = nch; r.B = M; r.K = D;
         r.slabs = g->slabs; r.slab_stride = act; r.S = S; r.bias = bias;
-        r.gate = g->mod + off_gate; r.gate_stride = g->Ntot;
+        r.gate = g->mod + off_gate; r.gate_stride = g->Ntot; r.pos_dev = g->ctr;
+        if (shared_u) { r.gate_u = g->mod_u + off_gate; r.gate_split = Bhalf; }
         return launch_resid(r, nch * MT, st);
     }
     int layer(int l) {
@@ -390,6 +423,7 @@ int wmar_rar_create(const wmar_rar_config* cfg, const char* const* names, const 
     TRY(g->alloc(&g->slabs, (size_t)MAX_SLABS * Mpad * D / 4));
     TRY(g->alloc(&g->qkv_slabs, Mpad * 3 * D / 4));
     TRY(g->alloc(&g->mod, Mpad * (size_t)g->Ntot));
+    TRY(g->alloc(&g->mod_u, (size_t)((g->T + 31) / 32) * 32 * (size_t)g->Ntot));
     TRY(g->alloc(&g->stats, (size_t)STAT_CHUNKS_MAX * Mpad * 2));
     const size_t kv = (size_t)L * g->Mmax * H * g->T * hd;
     TRY(g->alloc(&g->kcache, kv));
@@ -463,7 +497,24 @@ int wmar_rar_generate(wmar_rar* g, const wmar_wm_ctx* wm, const int64_t* class_i
     if (use_guidance) WMAR_HIP_CHECK(hipMemcpyAsync(g->cfg_scale, cfg_scale_host, (size_t)L * 4, hipMemcpyHostToDevice, st));
     WMAR_HIP_CHECK(hipStreamSynchronize(st));   // host staging vectors go out of scope
 
-    RarPlan p(g, M, (int)B, nullptr, st);
+    if (use_guidance && !g->mod_u_ready) {
+        // every unconditional row has the same condition: its adaLN modulations depend on the position only
+        const int MTt = (g->T + 31) / 32;
+        float4* tmp = nullptr;
+        WMAR_HIP_CHECK(hipMalloc(&tmp, (size_t)MTt * 32 * g->D * 4));
+        hipLaunchKernelGGL(k_rar_cond_rows, dim3((unsigned)(g->D / 8 * MTt)), dim3(64), 0, st, tmp, g->emb, g->tstep, none_id, g->T, MTt, g->D);
+        GemmArgs a{};
+        a.MT = MTt; a.B = MTt * 32; a.K = g->D; a.D = g->D; a.Wp = g->wada; a.Xp = tmp; a.KB = g->D / 8; a.NT = (int)(g->Ntot / 32);
+        a.bias = g->bada; a.logits = g->mod_u; a.V = (int)g->Ntot; a.pos_dev = g->ctr;
+        int rc = gemm_dispatch<EPI_LOGITS, false>(a, false, st);
+        hipError_t e = hipStreamSynchronize(st);
+        (void)hipFree(tmp);
+        if (rc) return rc;
+        if (e != hipSuccess) { set_error("unconditional adaLN table: %s", hipGetErrorString(e)); return WMAR_EHIP; }
+        g->mod_u_ready = true;
+    }
+    const bool shared_u = use_guidance != 0;
+    RarPlan p(g, M, (int)B, nullptr, st, shared_u);
     // position 0: the cls token (no logits needed)
     hipLaunchKernelGGL(k_set3, dim3(1), dim3(1), 0, st, g->ctr, 0, 0, 0);
     if (int rc = p.position(false, nullptr)) return rc;
@@ -479,7 +530,7 @@ int wmar_rar_generate(wmar_rar* g, const wmar_wm_ctx* wm, const int64_t* class_i
     if (use_guidance) { a.logits_uncond = g->logits + (long long)B * V; a.cfg_scale = g->cfg_scale; }
 
     auto one_step = [&](hipStream_t s) -> int {
-        RarPlan q(g, M, (int)B, nullptr, s);
+        RarPlan q(g, M, (int)B, nullptr, s, shared_u);
         int rc = q.position(true, g->logits);
         if (rc) return rc;
         if ((rc = launch_sample_fused(a, s))) return rc;
