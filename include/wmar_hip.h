@@ -206,6 +206,39 @@ int wmar_rar_generate(wmar_rar* g, const wmar_wm_ctx* wm, const int64_t* class_i
                       const float* cfg_scale_host, int32_t use_guidance, float temperature, const float* q_dev,
                       int64_t* tokens_out_dev, int32_t use_graph, void* stream);
 
+/* RAR generation with the Gumbel-key sampler below instead of multinomial + greenlist (BASELINE
+ * config "RAR-XL ... Gumbel-key watermark"; an EXTENSION -- the reference image code has no such
+ * path).  log_rs_dev float [V]: the fixed key (wmar_gumbel_key_build). */
+int wmar_rar_generate_gumbel(wmar_rar* g, const int64_t* class_ids_dev, int64_t B, const float* cfg_scale_host,
+                             int32_t use_guidance, float temperature, float top_p, int32_t top_k,
+                             const float* log_rs_dev, int64_t* tokens_out_dev, int32_t use_graph, void* stream);
+
+/* ----------------------------------------------------------------- Gumbel key (row G1)
+ * Aaronson-style sampling of wmar_audio/watermark/engine.py:29-75 (`gumbel_sample`) and its
+ * detector :123-134 (`gumbel_score_tok`).  The key of a row is rs = torch.rand(V, generator =
+ * CPU MT19937 seeded with the row's window hash) (engine.py:64-66); with ngram = 0 the hash is
+ * the seed itself (:17-18), so one key serves every row.
+ *
+ * wmar_gumbel_key_build (host): rs_host[v] = (mt.next() & 0xffffff) * 2^-24 (torch's fp32
+ * uniform), log_rs_host[v] = (float)log(rs) and score_host[v] = (float)-log(1 - rs).  Any output
+ * may be null. */
+int wmar_gumbel_key_build(uint64_t seed, int64_t vocab_size, float* rs_host, float* log_rs_host, float* score_host);
+
+/* next_token[b] = argmax_v rs[v]^(1/p[v]) with p = softmax(logits/temp) after the optional top-p
+ * (descending sort, drop where cumsum - p > top_p, renormalise) or else top-k (others := 1e-6,
+ * renormalise) -- engine.py:41-75.  The race is run as argmax log(rs[v]) * (1/p[v]) (monotone
+ * image; scores below log(2^-150) collapse to one class like the reference's fp32 underflow).
+ * use_sampling == 0 or temp <= 0: plain argmax(logits).  key_row_stride: elements between the
+ * keys of consecutive rows (0: one shared key).  V <= 16384. */
+int wmar_gumbel_sample(const float* logits_dev, int64_t B, int64_t V, const float* log_rs_dev, int64_t key_row_stride,
+                       int32_t use_sampling, float temp, float top_p, int32_t top_k, int64_t* tok_out_dev, void* stream);
+
+/* gumbel_score_tok for tokens int64 [B, L]: scores_f32_dev[b,l] = -log(1 - rs)[token] and
+ * scores_i64_dev[b,l] = that value truncated toward zero (what the reference returns, because it
+ * accumulates into zeros_like(tokens)).  Either output may be null. */
+int wmar_gumbel_score(const int64_t* tokens_dev, int64_t B, int64_t L, int64_t V, const float* score_key_dev,
+                      int64_t key_row_stride, int64_t* scores_i64_dev, float* scores_f32_dev, void* stream);
+
 /* ---------------------------------------------------------------------- VQGAN
  * Taming VQGAN (deps/taming/models/vqgan.py:30-73, modules/diffusionmodules/model.py:343-538,
  * modules/vqvae/quantize.py:272-331).  Tensors by key name relative to `first_stage_model.`

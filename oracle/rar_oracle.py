@@ -81,7 +81,8 @@ def default_q_source(step, B, V):
 @torch.no_grad()
 def generate(sd: Dict[str, T], cfg, condition: T, guidance_scale=4.0, guidance_scale_pow=0.0,
              randomize_temperature=1.0, key: Optional[W.KeyParams] = None, delta: float = 0.0,
-             q_source: Callable = default_q_source, record=None, draw_drop_mask: bool = True) -> T:
+             q_source: Callable = default_q_source, record=None, draw_drop_mask: bool = True,
+             sampler: Optional[Callable] = None) -> T:
     """RAR.generate (rar.py:408-459) with classifier-free guidance and the logit processor.
     condition int64 [B] class ids.  Returns int64 [B, image_seq_len]."""
     B = condition.shape[0]
@@ -107,6 +108,12 @@ def generate(sd: Dict[str, T], cfg, condition: T, guidance_scale=4.0, guidance_s
             mixed = ul + (cl - ul) * scales[step]
         else:
             mixed = cl
+        if sampler is not None:
+            # replacement sampler (Gumbel key, row G1): (mixed logits [B, V], step) -> int64 [B]
+            t = sampler(mixed, step).to(torch.long)
+            ids = torch.cat([ids, t.view(-1, 1)], dim=1)
+            tok_emb = sd["embeddings.weight"][torch.cat([t, t])]
+            continue
         lg = mixed.numpy()
         if key is not None:
             lg = W.process_logits(key, ids.numpy(), lg, delta)

@@ -47,6 +47,12 @@ def lib():
                                          C.c_int, C.c_int, C.c_int, C.c_double, i64p, C.c_int64, C.c_int64, f32p]
         L.wmo_sample_row.restype = C.c_int64
         L.wmo_sample_row.argtypes = [f32p, C.c_int64, C.c_double, C.c_int, C.c_double, f32p, C.c_void_p, C.c_void_p]
+        L.wmo_gumbel_key.restype = None
+        L.wmo_gumbel_key.argtypes = [C.c_uint64, C.c_int64, f32p]
+        L.wmo_gumbel_sample_row.restype = C.c_int64
+        L.wmo_gumbel_sample_row.argtypes = [f32p, C.c_int64, f32p, C.c_int, C.c_float, C.c_float, C.c_int]
+        L.wmo_gumbel_score.restype = C.c_float
+        L.wmo_gumbel_score.argtypes = [f32p, C.c_int64]
         L.wmo_betainc_int.restype = C.c_double
         L.wmo_betainc_int.argtypes = [C.c_int64, C.c_int64, C.c_double]
         L.wmo_detect_one.argtypes = [C.c_uint64, i64p, C.c_int64, i64p, C.c_int64, C.c_int64, C.c_double, C.c_int,
@@ -168,3 +174,36 @@ def key_table(key: KeyParams, row0: int, n_rows: int) -> np.ndarray:
     out = np.zeros((n_rows, words), dtype=np.uint32)
     lib().wmo_key_table(*key._common(), key.seed, row0, n_rows, out)
     return out
+
+
+# ------------------------------------------------------------------ Gumbel key (row G1)
+def gumbel_key(seed: int, vocab: int) -> np.ndarray:
+    """rs = torch.rand(vocab, generator=MT19937(seed)) (wmar_audio/watermark/engine.py:64-66)."""
+    out = np.zeros(vocab, dtype=np.float32)
+    lib().wmo_gumbel_key(C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), vocab, out)
+    return out
+
+
+def gumbel_sample(logits, window_hash, use_sampling=False, temp=1.0, top_p=0.0, top_k=0) -> np.ndarray:
+    """gumbel_sample of engine.py:29-75: logits float32 [B, V], window_hash int [B] -> tokens int64 [B]."""
+    logits = np.ascontiguousarray(np.asarray(logits, dtype=np.float32))
+    B, V = logits.shape
+    out = np.zeros(B, dtype=np.int64)
+    keys = {}
+    for b in range(B):
+        h = int(window_hash[b])
+        if h not in keys:
+            keys[h] = gumbel_key(h, V)
+        out[b] = lib().wmo_gumbel_sample_row(np.ascontiguousarray(logits[b]), V, keys[h], int(bool(use_sampling)),
+                                             float(temp), float(top_p), int(top_k))
+    return out
+
+
+def gumbel_score_tok(tokens, window_hash, vocab: int, truncate=True) -> np.ndarray:
+    """gumbel_score_tok of engine.py:123-134: tokens int64 [B] -> scores (int64-truncated like the reference, or fp32)."""
+    tokens = np.asarray(tokens, dtype=np.int64)
+    out = np.zeros(tokens.shape[0], dtype=np.float32)
+    for b in range(tokens.shape[0]):
+        rs = gumbel_key(int(window_hash[b]), vocab)
+        out[b] = lib().wmo_gumbel_score(rs, int(tokens[b]))
+    return out.astype(np.int64) if truncate else out

@@ -140,10 +140,52 @@ def rar_vectors(args, synth, wms, rs):
     print("wrote rar_vectors.npz", os.path.getsize(os.path.join(HERE, "rar_vectors.npz")), "bytes")
 
 
+def gumbel_vectors(args):
+    """Known answers of wmar_audio/watermark/engine.py (gumbel_sample, gumbel_score_tok, get_wm_window_hash)."""
+    import torch
+    sys.path.insert(0, os.path.join(args.ref, "wmar_audio"))
+    import moshi  # noqa: F401  (engine.py imports moshi.utils.sampling)
+    from watermark import engine as E
+
+    out = {}
+    V, B = 1024, 12
+    g = torch.Generator().manual_seed(99)
+    logits = (torch.randn(B, V, generator=g) * 3.0).float()
+    logits[3] = logits[3] * 4.0            # a peaked row
+    logits[5, 10] = logits[5, 700]         # an exact tie between two logits
+    out["gum_logits"] = logits.numpy()
+    same = E.get_wm_window_hash(torch.zeros(B, 0, dtype=torch.int64), seed=42)
+    assert same.tolist() == [42] * B
+    per_row = torch.tensor([7, 7, 123456789, 2 ** 31 - 2, 0, 1, 2 ** 32 + 5, 99, 1000, 31337, 5, 6], dtype=torch.int64)
+    out["gum_hash_same"] = same.numpy()
+    out["gum_hash_rows"] = per_row.numpy()
+    E.GENERATOR.manual_seed(42)
+    out["gum_rs_42"] = torch.rand(V, generator=E.GENERATOR).numpy()
+    cases = [("plain", 1.0, 0.0, 0), ("temp", 0.7, 0.0, 0), ("topk", 1.0, 0.0, 50), ("topp", 1.0, 0.9, 0),
+             ("topp_t", 0.8, 0.5, 0), ("topk1", 1.0, 0.0, 1)]
+    for hname, h in (("same", same), ("rows", per_row)):
+        for name, temp, top_p, top_k in cases:
+            tok = E.gumbel_sample(logits.clone(), h, use_sampling=True, temp=temp, top_p=top_p, top_k=top_k)
+            out[f"gum_tok_{hname}_{name}"] = tok.numpy().astype(np.int64)
+        out[f"gum_tok_{hname}_greedy"] = E.gumbel_sample(logits.clone(), h, use_sampling=False).numpy().astype(np.int64)
+    out["gum_cases"] = np.array([[t, p, k] for _, t, p, k in cases], dtype=np.float64)
+    out["gum_case_names"] = np.array([c[0] for c in cases])
+    toks = torch.arange(B, dtype=torch.int64) * 83 % V
+    out["gum_score_tokens"] = toks.numpy()
+    out["gum_score_same"] = E.gumbel_score_tok(toks, same, V).numpy()
+    out["gum_score_rows"] = E.gumbel_score_tok(toks, per_row, V).numpy()
+    np.savez_compressed(os.path.join(HERE, "gumbel_vectors.npz"), **out)
+    print("wrote gumbel_vectors.npz", os.path.getsize(os.path.join(HERE, "gumbel_vectors.npz")), "bytes")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default="", help="'gumbel': regenerate gumbel_vectors.npz only")
     args = ap.parse_args()
+    if args.only == "gumbel":
+        gumbel_vectors(args)
+        return
     tmp = tempfile.mkdtemp(prefix="wmar_stubs_")
     _stubs(tmp)
     sys.path[:0] = [tmp, args.ref, REPO]
@@ -365,6 +407,7 @@ def main():
     out["vq_codes_roundtrip"] = codes2.numpy()
 
     rar_vectors(args, synth, wms, rs)
+    gumbel_vectors(args)
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     sz = os.path.getsize(os.path.join(HERE, "reference_vectors.npz"))
     print("wrote reference_vectors.npz", sz, "bytes; key_kat.json")

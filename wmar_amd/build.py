@@ -16,6 +16,7 @@ LIB = os.path.join(HERE, "libwmar_hip.so")
 SOURCES = [
     ("keytable.cpp", []),
     ("watermark.hip", ["-ffp-contract=off"]),
+    ("gumbel.hip", ["-ffp-contract=off"]),
     ("gpt.hip", []),
     ("rar.hip", []),
     ("vqgan.hip", []),

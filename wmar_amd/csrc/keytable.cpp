@@ -4,6 +4,7 @@
 // The whole key is built ONCE as a bitmap table so that no per-step host work is left.
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <thread>
 #include <vector>
 
@@ -118,6 +119,20 @@ int64_t wmar_key_greenlist(const wmar_key_params* key, uint64_t seed, int64_t* o
     if (!key || !out_ids_host) return WMAR_EINVAL;
     Scratch sc;
     return greenlist(*key, seed, sc, out_ids_host);
+}
+
+int wmar_gumbel_key_build(uint64_t seed, int64_t vocab_size, float* rs_host, float* log_rs_host, float* score_host) {
+    WMAR_REQUIRE(vocab_size > 0, "gumbel_key_build: bad vocab");
+    // torch.rand(V, generator=g) on the CPU generator: one 32-bit draw per element, 24 mantissa
+    // bits kept (at::uniform_real_distribution<float>); manual_seed keeps the low 32 bits
+    Mt19937 g((uint32_t)(seed & 0xffffffffu));
+    for (int64_t v = 0; v < vocab_size; ++v) {
+        const float rs = (float)(g.next() & 0xffffffu) * 5.9604644775390625e-08f;
+        if (rs_host) rs_host[v] = rs;
+        if (log_rs_host) log_rs_host[v] = (float)std::log((double)rs);                  // -inf for rs == 0
+        if (score_host) score_host[v] = (float)(-std::log((double)(1.0f - rs)));
+    }
+    return WMAR_OK;
 }
 
 int wmar_key_table_build(const wmar_key_params* key, int64_t row0, int64_t n_rows, uint32_t* out_host,

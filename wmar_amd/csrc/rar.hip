@@ -471,10 +471,11 @@ int wmar_rar_forward_position(wmar_rar* g, const int64_t* tok_dev, const int64_t
     return p.position(true, logits_dev);
 }
 
-int wmar_rar_generate(wmar_rar* g, const wmar_wm_ctx* wm, const int64_t* class_ids_dev, int64_t B,
-                      const float* cfg_scale_host, int32_t use_guidance, float temperature, const float* q_dev,
-                      int64_t* tokens_out_dev, int32_t use_graph, void* stream) {
-    WMAR_REQUIRE(g && class_ids_dev && q_dev && tokens_out_dev, "rar_generate: null argument");
+static int rar_generate_impl(wmar_rar* g, const wmar_wm_ctx* wm, const int64_t* class_ids_dev, int64_t B,
+                             const float* cfg_scale_host, int32_t use_guidance, float temperature, const float* q_dev,
+                             const float* log_rs_dev, float top_p, int32_t top_k,
+                             int64_t* tokens_out_dev, int32_t use_graph, void* stream) {
+    WMAR_REQUIRE(g && class_ids_dev && (q_dev || log_rs_dev) && tokens_out_dev, "rar_generate: null argument");
     WMAR_REQUIRE(B >= 1 && B <= g->Bmax, "rar_generate: batch %lld outside 1..%d", (long long)B, g->Bmax);
     WMAR_REQUIRE(!use_guidance || cfg_scale_host, "rar_generate: guidance scales missing");
     if (wm) WMAR_REQUIRE(wm->table_dev && wm->vocab_size == g->V, "rar_generate: watermark vocab mismatch");
@@ -528,12 +529,17 @@ int wmar_rar_generate(wmar_rar* g, const wmar_wm_ctx* wm, const int64_t* class_i
     a.scratch = g->scratch; a.tok_out = (long long*)tokens_out_dev; a.tok_out_stride = L;
     a.past_append = g->ids; a.trace = nullptr; a.B = B;
     if (use_guidance) { a.logits_uncond = g->logits + (long long)B * V; a.cfg_scale = g->cfg_scale; }
+    GumbelArgs ga{};
+    ga.logits = g->logits; ga.logits_uncond = a.logits_uncond; ga.cfg_scale = a.cfg_scale; ga.step_dev = g->ctr + 1;
+    ga.t_dev = g->ctr + 2; ga.V = V; ga.B = B; ga.log_rs = log_rs_dev; ga.key_row_stride = 0;
+    ga.use_sampling = 1; ga.temp = temperature; ga.top_p = top_p; ga.top_k = top_k;
+    ga.tok_out = (long long*)tokens_out_dev; ga.tok_out_stride = L; ga.past_append = g->ids; ga.past_stride = L;
 
     auto one_step = [&](hipStream_t s) -> int {
         RarPlan q(g, M, (int)B, nullptr, s, shared_u);
         int rc = q.position(true, g->logits);
         if (rc) return rc;
-        if ((rc = launch_sample_fused(a, s))) return rc;
+        if ((rc = log_rs_dev ? launch_gumbel_sample(ga, s) : launch_sample_fused(a, s))) return rc;
         hipLaunchKernelGGL(k_advance3, dim3(1), dim3(1), 0, s, g->ctr);
         return launch_status("k_advance3");
     };
@@ -554,6 +560,23 @@ int wmar_rar_generate(wmar_rar* g, const wmar_wm_ctx* wm, const int64_t* class_i
             if (int rc = one_step(st)) return rc;
     }
     return WMAR_OK;
+}
+
+int wmar_rar_generate(wmar_rar* g, const wmar_wm_ctx* wm, const int64_t* class_ids_dev, int64_t B,
+                      const float* cfg_scale_host, int32_t use_guidance, float temperature, const float* q_dev,
+                      int64_t* tokens_out_dev, int32_t use_graph, void* stream) {
+    WMAR_REQUIRE(q_dev, "rar_generate: null argument");
+    return rar_generate_impl(g, wm, class_ids_dev, B, cfg_scale_host, use_guidance, temperature, q_dev, nullptr, 0.f, 0,
+                             tokens_out_dev, use_graph, stream);
+}
+
+int wmar_rar_generate_gumbel(wmar_rar* g, const int64_t* class_ids_dev, int64_t B, const float* cfg_scale_host,
+                             int32_t use_guidance, float temperature, float top_p, int32_t top_k,
+                             const float* log_rs_dev, int64_t* tokens_out_dev, int32_t use_graph, void* stream) {
+    WMAR_REQUIRE(log_rs_dev, "rar_generate_gumbel: null key");
+    WMAR_REQUIRE(g && g->V <= 16384, "rar_generate_gumbel: codebook larger than 16384");
+    return rar_generate_impl(g, nullptr, class_ids_dev, B, cfg_scale_host, use_guidance, temperature, nullptr, log_rs_dev, top_p,
+                             top_k, tokens_out_dev, use_graph, stream);
 }
 
 }  // extern "C"

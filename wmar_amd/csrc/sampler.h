@@ -56,4 +56,25 @@ struct SampArgs {
 
 int launch_sample_fused(const SampArgs& a, hipStream_t st);
 
+// Gumbel-key sampler (gumbel.hip): same step / append plumbing as SampArgs.
+struct GumbelArgs {
+    const float* logits;
+    const float* logits_uncond;  // nullable (guidance, as above)
+    const float* cfg_scale;
+    const int* step_dev;         // nullable
+    const int* t_dev;            // nullable: current length for past_append
+    long long V, B;
+    const float* log_rs;         // key rows: log_rs + b * key_row_stride
+    long long key_row_stride;
+    int use_sampling;
+    float temp, top_p;
+    int top_k;
+    long long* tok_out;          // tok_out[b*tok_out_stride + step]
+    long long tok_out_stride;
+    long long* past_append;      // nullable: past_append[b*past_stride + t] = token
+    long long past_stride;
+};
+
+int launch_gumbel_sample(const GumbelArgs& a, hipStream_t st);
+
 }  // namespace wmar

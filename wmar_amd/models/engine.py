@@ -233,6 +233,26 @@ class RAREngine:
                 float(temperature), q.data_ptr(), out.data_ptr(), 1 if use_graph else 0, _lib.stream_ptr(self.device)))
         return out
 
+    def generate_gumbel(self, class_ids, log_rs, cfg_scales, temperature=1.0, top_p=0.0, top_k=0, use_graph=True):
+        """RAR.generate with the Gumbel-key sampler (extension, include/wmar_hip.h wmar_rar_generate_gumbel)."""
+        _require_cuda(class_ids, "class ids")
+        _require_cuda(log_rs, "gumbel key")
+        class_ids = class_ids.to(torch.int64).contiguous().view(-1)
+        B = class_ids.shape[0]
+        Ls, V = self.cfg.image_seq_len, self.cfg.codebook_size
+        assert log_rs.shape == (V,) and log_rs.dtype == torch.float32 and log_rs.is_contiguous()
+        out = torch.empty(B, Ls, dtype=torch.int64, device=self.device)
+        sc = None
+        if cfg_scales is not None:
+            sc = cfg_scales.detach().to("cpu", torch.float32).contiguous()
+            assert sc.numel() == Ls
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.wmar_rar_generate_gumbel(
+                self._h, class_ids.data_ptr(), B, C.cast(sc.data_ptr(), C.POINTER(C.c_float)) if sc is not None else None,
+                1 if sc is not None else 0, float(temperature), float(top_p), int(top_k), log_rs.data_ptr(), out.data_ptr(),
+                1 if use_graph else 0, _lib.stream_ptr(self.device)))
+        return out
+
 
 class MaskgitVQEngine:
     """MaskGIT-VQGAN tokenizer of RAR; replaces PretrainedTokenizer.encode / decode_tokens

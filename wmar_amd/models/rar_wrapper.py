@@ -13,6 +13,7 @@ import torch
 
 from ..utils.synth import MASKGIT_VQ, RAR_XL, MaskgitVQConfig, RARConfig, synth_maskgit_state, synth_rar_state
 from .armm_wrapper import AutoregressiveMultimodalModelWrapper
+from ..watermarking.gumbel_watermark import GumbelWatermark
 from .engine import MaskgitVQEngine, RAREngine
 
 _ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
@@ -113,10 +114,18 @@ class RarARMMWrapper(AutoregressiveMultimodalModelWrapper):
         conditioning = torch.as_tensor(conditioning, device=self.model.device).view(-1)
         cfg = self.model.cfg
         B = conditioning.shape[0]
-        wm_ctx = self.watermarker.wm_ctx() if apply_watermark else None
         scales = cfg_scales(cfg.image_seq_len, 4.0, 0.0)
         out = torch.empty(B, cfg.image_seq_len, dtype=torch.int64, device=self.model.device)
         mb = self.model.max_batch
+        if apply_watermark and isinstance(self.watermarker, GumbelWatermark):
+            # Gumbel key: the key replaces the sampling noise (extension)
+            w = self.watermarker
+            for b0 in range(0, B, mb):
+                b1 = min(B, b0 + mb)
+                out[b0:b1] = self.model.engine.generate_gumbel(conditioning[b0:b1], w.log_rs, scales, w.temperature, w.top_p,
+                                                               w.top_k, use_graph=self.use_graph)
+            return out.detach()
+        wm_ctx = self.watermarker.wm_ctx() if apply_watermark else None
         if q is None and B > mb:
             q = self.draw_noise(B)
         for b0 in range(0, B, mb):
