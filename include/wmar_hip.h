@@ -239,6 +239,58 @@ int wmar_gumbel_sample(const float* logits_dev, int64_t B, int64_t V, const floa
 int wmar_gumbel_score(const int64_t* tokens_dev, int64_t B, int64_t L, int64_t V, const float* score_key_dev,
                       int64_t key_row_stride, int64_t* scores_i64_dev, float* scores_f32_dev, void* stream);
 
+/* ------------------------------------------------------------------ Chameleon (row C1)
+ * Chameleon / Anole text->image decode: deps/chameleon/inference/transformer.py:288-353
+ * (Transformer), chameleon.py:299-389 (ImageDecoder), logits_processor.py:135-156, 312-336,
+ * token_selector.py:26-47.  bf16 weights and activations, fp32 accumulation.  Tensors by the
+ * checkpoint's key names (tok_embeddings.weight, layers.N.attention.{wqkv,wo}.weight,
+ * layers.N.attention.{q,k}_normalization.{weight,bias}, layers.N.feed_forward.{w13,w2}.weight,
+ * layers.N.{attention,ffn}_norm.weight, norm.weight, output.weight); all bf16 (tensors_bf16 = 1,
+ * the reference's storage) or all fp32 (rounded to bf16 at pack time). */
+typedef struct wmar_cham_config {
+    int32_t dim, n_layers, n_heads, n_kv_heads, vocab_size;
+    int32_t ffn_hidden;        /* FeedForward hidden size after the multiple_of rounding (transformer.py:175-179) */
+    float norm_eps, rope_theta;
+    int32_t qk_normalization;  /* LayerNorm(head_dim) on q and k (transformer.py:74-77) */
+    int32_t swin_norm;         /* must be 0 (the 30B block order is not built) */
+    int32_t max_rows;          /* sequences per step = 3 * images per call */
+    int32_t max_seq_len;       /* prompt + generated tokens per sequence */
+    int32_t tensors_bf16;
+} wmar_cham_config;
+
+typedef struct wmar_cham_sample_params {
+    float temperature;
+    double top_p;                                     /* < 0: off */
+    float guidance_scale_text, guidance_scale_image;  /* Options.Image.cfg: 3.0 / 1.2 */
+    int32_t use_graph;
+} wmar_cham_sample_params;
+
+typedef struct wmar_cham wmar_cham;
+
+int wmar_cham_create(const wmar_cham_config* cfg, const char* const* names, const void* const* tensors_dev,
+                     int32_t n_tensors, void* stream, wmar_cham** out);
+void wmar_cham_destroy(wmar_cham* g);
+int64_t wmar_cham_device_bytes(const wmar_cham* g);
+
+/* One token per sequence: row m consumes tok_dev[m] at position pos_dev[m] (its KV cache must hold
+ * positions 0..pos-1) -> logits_dev float [M, vocab] (nullable: cache update only).  This is
+ * Transformer.forward_with_attn_bias with q_seqlen = 1 per sequence (model_adapter.py:106-113);
+ * a prompt is prefilled by calling it once per position. */
+int wmar_cham_forward_tokens(wmar_cham* g, const int64_t* tok_dev, const int32_t* pos_dev, int64_t M, float* logits_dev,
+                             void* stream);
+
+/* ImageDecoder (chameleon.py:299-389) for B prompts: prompt_tokens_host = the 3B token lists of
+ * _split_inputs_for_cfg (:351-372; full-conditioned, image-conditioned, unconditioned) laid end to
+ * end, prompt_lens_host int32 [3B].  Per generated token: guidance mix -> watermark bias ->
+ * allow-only (allow_dev: bit per vocabulary entry, nullable) -> temperature -> top-p -> softmax ->
+ * multinomial on the first stream (q_dev float [n_tokens, B, vocab] Exp(1) noise, one [B, vocab]
+ * draw per token as probs.multinomial makes).  tokens_out_dev int64 [B, n_tokens] (vocabulary ids).
+ * The watermark context is the sequence so far (last prompt token first). */
+int wmar_cham_generate_image(wmar_cham* g, const wmar_wm_ctx* wm, const int64_t* prompt_tokens_host,
+                             const int32_t* prompt_lens_host, int64_t B, const wmar_cham_sample_params* sp,
+                             const uint32_t* allow_dev, const float* q_dev, int32_t n_tokens, int64_t* tokens_out_dev,
+                             void* stream);
+
 /* ---------------------------------------------------------------------- VQGAN
  * Taming VQGAN (deps/taming/models/vqgan.py:30-73, modules/diffusionmodules/model.py:343-538,
  * modules/vqvae/quantize.py:272-331).  Tensors by key name relative to `first_stage_model.`

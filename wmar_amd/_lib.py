@@ -21,6 +21,7 @@ SYMBOLS = [
     "wmar_rar_device_bytes", "wmar_rar_forward_position", "wmar_rar_generate", "wmar_vq_create", "wmar_vq_destroy", "wmar_vq_device_bytes",
     "wmar_vq_decode", "wmar_vq_encode", "wmar_mvq_create", "wmar_mvq_destroy", "wmar_mvq_device_bytes", "wmar_mvq_decode",
     "wmar_mvq_encode", "wmar_gumbel_key_build", "wmar_gumbel_sample", "wmar_gumbel_score", "wmar_rar_generate_gumbel",
+    "wmar_cham_create", "wmar_cham_destroy", "wmar_cham_device_bytes", "wmar_cham_forward_tokens", "wmar_cham_generate_image",
 ]
 
 WMAR_ESHORT = -3
@@ -65,6 +66,18 @@ class MvqConfig(C.Structure):
     _fields_ = [("hidden_channels", C.c_int32), ("num_res_blocks", C.c_int32), ("resolution", C.c_int32),
                 ("num_channels", C.c_int32), ("z_channels", C.c_int32), ("num_embeddings", C.c_int32),
                 ("n_levels", C.c_int32), ("channel_mult", C.c_int32 * 8), ("max_batch", C.c_int32)]
+
+
+class ChamConfig(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("n_layers", C.c_int32), ("n_heads", C.c_int32), ("n_kv_heads", C.c_int32),
+                ("vocab_size", C.c_int32), ("ffn_hidden", C.c_int32), ("norm_eps", C.c_float), ("rope_theta", C.c_float),
+                ("qk_normalization", C.c_int32), ("swin_norm", C.c_int32), ("max_rows", C.c_int32),
+                ("max_seq_len", C.c_int32), ("tensors_bf16", C.c_int32)]
+
+
+class ChamSampleParams(C.Structure):
+    _fields_ = [("temperature", C.c_float), ("top_p", C.c_double), ("guidance_scale_text", C.c_float),
+                ("guidance_scale_image", C.c_float), ("use_graph", C.c_int32)]
 
 
 class WmarError(RuntimeError):
@@ -132,6 +145,13 @@ def load():
         L.wmar_vq_device_bytes.argtypes = [vp]
         L.wmar_vq_decode.argtypes = [vp, vp, i64, vp, vp]
         L.wmar_vq_encode.argtypes = [vp, vp, i64, vp, vp, vp]
+    L.wmar_cham_create.argtypes = [C.POINTER(ChamConfig), C.POINTER(C.c_char_p), C.POINTER(vp), i32, vp, C.POINTER(vp)]
+    L.wmar_cham_destroy.argtypes = [vp]
+    L.wmar_cham_destroy.restype = None
+    L.wmar_cham_device_bytes.restype = i64
+    L.wmar_cham_device_bytes.argtypes = [vp]
+    L.wmar_cham_forward_tokens.argtypes = [vp, vp, vp, i64, vp, vp]
+    L.wmar_cham_generate_image.argtypes = [vp, C.POINTER(WmCtx), vp, vp, i64, C.POINTER(ChamSampleParams), vp, vp, i32, vp, vp]
     L.wmar_mvq_create.argtypes = [C.POINTER(MvqConfig), C.POINTER(C.c_char_p), C.POINTER(vp), i32, vp, C.POINTER(vp)]
     L.wmar_mvq_destroy.argtypes = [vp]
     L.wmar_mvq_destroy.restype = None

@@ -19,6 +19,7 @@ SOURCES = [
     ("gumbel.hip", ["-ffp-contract=off"]),
     ("gpt.hip", []),
     ("rar.hip", []),
+    ("cham.hip", []),
     ("vqgan.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

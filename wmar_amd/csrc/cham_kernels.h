@@ -1,0 +1,552 @@
+// Device kernels of the Chameleon (Llama-style, bf16) decode engine for gfx950 -- SURVEY.md
+// section 8a row C1.  Reference: deps/chameleon/inference/transformer.py:37-353 (Attention with
+// qk LayerNorm + RoPE + KV cache, SwiGLU FeedForward, RMSNorm blocks, output head).
+//
+// Decode at 3*B rows (three guidance streams) is HBM-bound: 13.5 GB of bf16 weights and about as
+// much KV cache per step against ~1 GFLOP/row, so the GEMM is built around the weight stream:
+//   * weights `W[N][K]` -> `Wp[n/32][k/16][lane][8 bf16]`: one wave-wide 16-byte load (1 KiB
+//     contiguous) is the A operand of one v_mfma_f32_32x32x16_bf16 per row tile;
+//   * activations `X[M][K]` -> `Xp[k/16][m/32][lane][8 bf16]` (the B operand); a workgroup's four
+//     waves own four column tiles over the SAME k range, so the activation chunk is staged once in
+//     LDS (double buffered, one barrier per 256-column chunk) instead of four times through L1;
+//   * the 32 weight rows of a tile are permuted at pack time so that the 16 accumulator registers
+//     of a lane are two runs of 8 consecutive output features: every epilogue stores the next
+//     layer's operand layout directly (16 B of bf16 or 32 B of fp32 per lane per run);
+//   * RMSNorm's weight is folded into the following GEMM's weights; 1/rms is applied to the
+//     accumulator (by the epilogue or by the consumer of the split-K slabs);
+//   * SwiGLU: a w13 tile interleaves 16 rows of w1 with the matching 16 rows of w3, so
+//     silu(x1)*x3 happens in registers and lands as one k-block of w2's input.
+// Rounding points follow the reference's bf16 module boundaries (Linear outputs, LayerNorm, RoPE,
+// SiLU, products, residual adds, attention output are rounded to bf16; accumulation is fp32).
+#pragma once
+#include "decoder_host.h"
+
+namespace wmar {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// streamed-once data (weights): non-temporal 16-byte load
+__device__ __forceinline__ uint4 ld_nt_u4(const uint4* p) {
+    u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+__device__ __forceinline__ uint32_t bf_round_bits(float f) {   // fp32 -> bf16 bits, round to nearest even
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float bf_round(float f) { return __uint_as_float(bf_round_bits(f) << 16); }
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ void bf_unpack8(const uint4& v, float* f) {
+    f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
+    f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
+}
+__device__ __forceinline__ uint4 bf_pack8(const float* f) {   // rounds
+    uint4 v;
+    v.x = bf_round_bits(f[0]) | (bf_round_bits(f[1]) << 16);
+    v.y = bf_round_bits(f[2]) | (bf_round_bits(f[3]) << 16);
+    v.z = bf_round_bits(f[4]) | (bf_round_bits(f[5]) << 16);
+    v.w = bf_round_bits(f[6]) | (bf_round_bits(f[7]) << 16);
+    return v;
+}
+
+// MFMA row i of a 32-row tile carries output feature cham_row_feature(i) of that tile.
+__host__ __device__ __forceinline__ int cham_row_feature(int i) {
+    const int g = i >> 3, h = (i >> 2) & 1, r = i & 3;
+    return 16 * (g >> 1) + 8 * h + 4 * (g & 1) + r;
+}
+
+// ------------------------------------------------------------------------------- packing
+// src: [N][K] bf16 (src_bf16) or fp32.  mode 0: tile nt holds rows nt*32 + feature.
+// mode 1 (w13, rows [0,Hd) = w1, [Hd,2Hd) = w3): tile nt holds w1 rows 16nt..16nt+15 as
+// features 0..15 and w3 rows 16nt..16nt+15 as features 16..31.
+// gamma (nullable, [K], same dtype as src): W'[n][k] = bf16(W[n][k] * gamma[k]).
+struct BPackArgs {
+    const void* src; const void* gamma; uint4* dst;
+    int N, K, mode, Hd, src_bf16;
+};
+
+static __global__ __launch_bounds__(64) void k_bpack(BPackArgs a) {
+    const int KB = a.K / 16;
+    const int nt = blockIdx.x / KB, kb = blockIdx.x % KB;
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const int f = cham_row_feature(i);
+    long long row;
+    if (a.mode == 0) row = (long long)nt * 32 + f;
+    else row = f < 16 ? (long long)nt * 16 + f : (long long)a.Hd + (long long)nt * 16 + (f - 16);
+    const int k0 = kb * 16 + 8 * h;
+    float v[8], gm[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gm[j] = 1.0f;
+    if (row < a.N) {
+        if (a.src_bf16) {
+            const uint4 w = *(const uint4*)((const uint16_t*)a.src + row * a.K + k0);
+            bf_unpack8(w, v);
+            if (a.gamma) { const uint4 g4 = *(const uint4*)((const uint16_t*)a.gamma + k0); bf_unpack8(g4, gm); }
+        } else {
+            const float* s = (const float*)a.src + row * a.K + k0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = s[j];
+            if (a.gamma)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gm[j] = ((const float*)a.gamma)[k0 + j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+    if (a.gamma)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * gm[j];
+    a.dst[((long long)nt * KB + kb) * 64 + lane] = bf_pack8(v);
+}
+
+// fp32 copy of a (possibly bf16) vector
+static __global__ void k_to_f32(const void* src, float* dst, long long n, int src_bf16) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    dst[i] = src_bf16 ? __uint_as_float((uint32_t)((const uint16_t*)src)[i] << 16) : ((const float*)src)[i];
+}
+// bf16 copy of a (possibly fp32) matrix (embedding table)
+static __global__ void k_to_bf16(const void* src, uint16_t* dst, long long n, int src_bf16) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    dst[i] = src_bf16 ? ((const uint16_t*)src)[i] : (uint16_t)bf_round_bits(((const float*)src)[i]);
+}
+
+// ---------------------------------------------------------------------- row statistics
+// 1/rms of row m from the per-chunk fp64 sums of squares: rsqrt(mean(x^2) + eps)  (xformers RMSNorm)
+__device__ __forceinline__ float cham_rstd(const double* __restrict__ ssq, int n_chunks, int Mpad, int m, int K, float eps) {
+    double s = 0;
+    for (int c0 = 0; c0 < n_chunks; c0 += 16) {
+        double v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = ssq[(long long)min(c0 + i, n_chunks - 1) * Mpad + m];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (c0 + i < n_chunks) s += v[i];
+    }
+    return rsqrtf((float)(s / (double)K) + eps);
+}
+
+// ------------------------------------------------------------------------------- GEMM
+constexpr int BG_KC = 16;        // k-blocks (of 16) per staged activation chunk: 256 columns
+enum { BEPI_SLAB = 0, BEPI_SWIGLU = 1, BEPI_LOGITS = 2 };
+
+struct BGemmArgs {
+    const uint4* Wp;       // [NT][KB][64]
+    const uint4* Xp;       // [KB][MT][64]
+    int KB, NT, S, M;
+    float* slabs;          // BEPI_SLAB: [S][NT*2][MT][64][8] fp32 partial sums
+    long long slab_stride; // floats
+    uint4* out_packed;     // BEPI_SWIGLU: [NT][MT][64] bf16x8
+    float* logits;         // BEPI_LOGITS: [M][V]
+    int V;
+    const double* ssq; int n_chunks; int K; float eps;   // 1/rms of the input rows (SWIGLU, LOGITS)
+};
+
+template <int MT, int EPI>
+__global__ __launch_bounds__(256) void k_bgemm(BGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint4 xs[];   // [2][BG_KC][MT][64]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int NG = (a.NT + 3) / 4;
+    const int ng = blockIdx.x % NG, s = blockIdx.x / NG;
+    const int nt = ng * 4 + w;
+    const bool live = nt < a.NT;
+    const int ntc = live ? nt : a.NT - 1;
+    const int kb0 = (int)((long long)s * a.KB / a.S), kb1 = (int)((long long)(s + 1) * a.KB / a.S);
+    const int nchunk = (kb1 - kb0 + BG_KC - 1) / BG_KC;
+    const uint4* Wp = a.Wp + (long long)ntc * a.KB * 64 + lane;
+    constexpr int XPT = BG_KC * MT / 4;       // uint4 per thread per chunk (256 threads)
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    float rstd[MT];
+    if (EPI != BEPI_SLAB) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) rstd[i] = cham_rstd(a.ssq, a.n_chunks, MT * 32, i * 32 + (lane & 31), a.K, a.eps);
+    }
+
+    uint4 wA[BG_KC], wB[BG_KC], xr[XPT];
+    // k-blocks past the slice end are clamped: they reload the last block and are skipped by the MFMA loop
+#define CH_LOADW(WB, C)                                                                   \
+    _Pragma("unroll") for (int u = 0; u < BG_KC; ++u) {                                   \
+        const int kk = min(kb0 + (C) * BG_KC + u, kb1 - 1);                               \
+        WB[u] = ld_nt_u4(Wp + (long long)kk * 64);                      \
+    }
+#define CH_LOADX(C)                                                                       \
+    _Pragma("unroll") for (int u = 0; u < XPT; ++u) {                                     \
+        const int e = threadIdx.x + u * 256;              /* element of [BG_KC][MT][64] */ \
+        const int kk = min(kb0 + (C) * BG_KC + e / (MT * 64), kb1 - 1);                   \
+        xr[u] = a.Xp[(long long)kk * (MT * 64) + e % (MT * 64)];                          \
+    }
+#define CH_STOREX(BUF)                                                                    \
+    _Pragma("unroll") for (int u = 0; u < XPT; ++u) xs[(BUF) * (BG_KC * MT * 64) + threadIdx.x + u * 256] = xr[u];
+#define CH_MMA1(WB, BUF, U)                                                               \
+    {                                                                                     \
+        const bf16x8 wv = __builtin_bit_cast(bf16x8, WB[U]);                              \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                  \
+            const uint4 xv = xs[(BUF) * (BG_KC * MT * 64) + ((U) * MT + i) * 64 + lane];  \
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, __builtin_bit_cast(bf16x8, xv), acc[i], 0, 0, 0); \
+        }                                                                                 \
+    }
+#define CH_MMA(WB, BUF, C)                                                                \
+    {                                                                                     \
+        const int nk = kb1 - (kb0 + (C) * BG_KC);                                         \
+        if (nk >= BG_KC) {                                                                \
+            _Pragma("unroll") for (int u = 0; u < BG_KC; ++u) CH_MMA1(WB, BUF, u)         \
+        } else {                                                                          \
+            _Pragma("unroll") for (int u = 0; u < BG_KC; ++u)                             \
+                if (u < nk) CH_MMA1(WB, BUF, u)                                           \
+        }                                                                                 \
+    }
+    CH_LOADW(wA, 0)
+    CH_LOADX(0)
+    __builtin_amdgcn_sched_barrier(0);
+    CH_STOREX(0)
+    __syncthreads();
+    for (int c = 0; c < nchunk; c += 2) {
+        if (c + 1 < nchunk) { CH_LOADW(wB, c + 1) CH_LOADX(c + 1) }
+        __builtin_amdgcn_sched_barrier(0);
+        CH_MMA(wA, 0, c)
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < nchunk) { CH_STOREX(1) }
+        __syncthreads();
+        if (c + 1 >= nchunk) break;
+        if (c + 2 < nchunk) { CH_LOADW(wA, c + 2) CH_LOADX(c + 2) }
+        __builtin_amdgcn_sched_barrier(0);
+        CH_MMA(wB, 1, c + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < nchunk) { CH_STOREX(0) }
+        __syncthreads();
+    }
+#undef CH_LOADW
+#undef CH_LOADX
+#undef CH_STOREX
+#undef CH_MMA
+#undef CH_MMA1
+    if (!live) return;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        if (EPI == BEPI_SLAB) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float* dst = a.slabs + (long long)s * a.slab_stride + ((((long long)nt * 2 + b) * MT + i) * 64 + lane) * 8;
+                *(float4*)dst = make_float4(acc[i][8 * b], acc[i][8 * b + 1], acc[i][8 * b + 2], acc[i][8 * b + 3]);
+                *(float4*)(dst + 4) = make_float4(acc[i][8 * b + 4], acc[i][8 * b + 5], acc[i][8 * b + 6], acc[i][8 * b + 7]);
+            }
+        } else if (EPI == BEPI_SWIGLU) {
+            // x13 = bf16(w13 x); silu and the product are bf16 ops (FeedForward.forward, transformer.py:214-216)
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x1 = bf_round(rstd[i] * acc[i][j]);
+                const float x3 = bf_round(rstd[i] * acc[i][8 + j]);
+                const float sl = bf_round(x1 / (1.0f + expf(-x1)));
+                o[j] = sl * x3;
+            }
+            a.out_packed[((long long)nt * MT + i) * 64 + lane] = bf_pack8(o);
+        } else {
+            const int m = i * 32 + (lane & 31);
+            if (m < a.M) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float* dst = a.logits + (long long)m * a.V + nt * 32 + 16 * b + 8 * h;
+                    float o[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = bf_round(rstd[i] * acc[i][8 * b + j]);   // logits.float() of a bf16 Linear
+                    *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+                    *(float4*)(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------- embedding / residual update
+// x = tok_embeddings[tok[m]] (bf16), per-chunk sums of squares.  One workgroup per (chunk of 16
+// k-blocks, row tile); wave w takes k-blocks w, w+4, ...
+struct ChamResidArgs {
+    uint4* x;                   // [KB][MT][64]
+    const float* slabs; long long slab_stride; int S;   // residual branch: sum of S fp32 slabs, rounded to bf16 first
+    const uint16_t* emb;        // embed: [V][K] bf16
+    const long long* tok;       // [M]
+    double* ssq;                // [n_chunks][Mpad]
+    int KB, MT, M, K;
+};
+
+template <bool EMBED>
+__global__ __launch_bounds__(256) void k_cham_resid(ChamResidArgs a) {
+    __shared__ double red[4][32];
+    const int c = blockIdx.x / a.MT, mt = blockIdx.x % a.MT;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = mt * 32 + (lane & 31), h = lane >> 5;
+    const int kb0 = c * 16, kb1 = min(a.KB, kb0 + 16);
+    const long long tk = (EMBED && m < a.M) ? a.tok[m] : 0;
+    double ss = 0.0;
+    for (int kb = kb0 + w; kb < kb1; kb += 4) {
+        const long long idx = ((long long)kb * a.MT + mt) * 64 + lane;
+        float r[8];
+        if (EMBED) {
+            const uint4 e = *(const uint4*)(a.emb + tk * a.K + kb * 16 + 8 * h);
+            bf_unpack8(e, r);
+            if (m >= a.M)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = 0.f;
+        } else {
+            float xv[8], br[8];
+            bf_unpack8(a.x[idx], xv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) br[j] = 0.f;
+            for (int sidx = 0; sidx < a.S; ++sidx) {
+                const float* sp = a.slabs + (long long)sidx * a.slab_stride + idx * 8;
+                const float4 p0 = *(const float4*)sp, p1 = *(const float4*)(sp + 4);
+                br[0] += p0.x; br[1] += p0.y; br[2] += p0.z; br[3] += p0.w;
+                br[4] += p1.x; br[5] += p1.y; br[6] += p1.z; br[7] += p1.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = bf_round(xv[j] + bf_round(br[j]));   // h = x + Linear(...) in bf16
+        }
+        a.x[idx] = bf_pack8(r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += (double)r[j] * r[j];
+    }
+    ss += __shfl_xor(ss, 32);
+    if (lane < 32) red[w][lane] = ss;
+    __syncthreads();
+    if (threadIdx.x < 32)
+        a.ssq[(long long)c * a.MT * 32 + mt * 32 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// ------------------------------------------------------------------------ decode attention
+struct ChamAttnArgs {
+    const float* qkv_slabs; long long slab_stride; int S;   // [S][(D + 2*Dkv)/16][MT][64][8]
+    const double* ssq; int n_chunks; int K; float eps;      // attention_norm statistics of the input rows
+    const float *qn_w, *qn_b, *kn_w, *kn_b;                 // [hd] LayerNorm(head_dim) of q and k; null: no qk normalisation
+    uint16_t* kcache; uint16_t* vcache;                     // [M][Hkv][Tmax][hd] bf16 (this layer)
+    uint4* y;                                               // packed [D/16][MT][64]
+    const int* pos;                                         // [M] position of each row's token
+    int D, H, Hkv, Tmax, MT;
+    float scale, theta;
+};
+
+template <int HD, int NWA>
+__global__ __launch_bounds__(NWA * 64) void k_cham_attn(ChamAttnArgs a) {
+    constexpr int LPR = HD / 8;            // lanes per cached row (8 bf16 each)
+    constexpr int RPI = 64 / LPR;          // rows per wave-wide load
+    constexpr int CH = 8;
+    constexpr int ROWS = CH * RPI;
+    __shared__ __attribute__((aligned(16))) float part[NWA][HD + 4];
+    __shared__ __attribute__((aligned(16))) float qkv_s[3][HD];
+    const int m = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const int hk = h / (a.H / a.Hkv);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int P = a.pos[m];
+    const int T = P + 1;
+    const int sub = lane % LPR, rsel = lane / LPR;
+    uint16_t* Kc = a.kcache + (((long long)m * a.Hkv + hk) * a.Tmax) * HD + sub * 8;
+    uint16_t* Vc = a.vcache + (((long long)m * a.Hkv + hk) * a.Tmax) * HD + sub * 8;
+    const int nchunk = (T + ROWS - 1) / ROWS;
+
+#define CA_LOAD(KB_, VB_, C0)                                                             \
+    _Pragma("unroll") for (int u = 0; u < CH; ++u) {                                      \
+        const int t = min((C0) * ROWS + u * RPI + rsel, T - 1);                           \
+        KB_[u] = *(const uint4*)(Kc + (long long)t * HD);                                 \
+        VB_[u] = *(const uint4*)(Vc + (long long)t * HD);                                 \
+    }
+    uint4 kA[CH], vA[CH], kB[CH], vB[CH];
+    if (w < nchunk) { CA_LOAD(kA, vA, w) }
+    __builtin_amdgcn_sched_barrier(0);
+    if (w == 0) {
+        // 1/rms of this row (one statistics chunk per lane), the q/k/v columns of this head from the slabs
+        double ssum = 0;
+        for (int c = lane; c < a.n_chunks; c += 64) ssum += a.ssq[(long long)c * a.MT * 32 + m];
+        float v3[3][8];
+        if (rsel == 0) {
+            const int mt = m >> 5;
+#pragma unroll
+            for (int which = 0; which < 3; ++which) {
+                const int n = (which == 0 ? h * HD : (which == 1 ? a.D + hk * HD : a.D + a.Hkv * HD + hk * HD)) + sub * 8;
+                const long long idx = ((((long long)(n >> 4)) * a.MT + mt) * 64 + (m & 31) + 32 * ((n >> 3) & 1)) * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v3[which][j] = 0.f;
+                for (int sidx = 0; sidx < a.S; ++sidx) {
+                    const float* sp = a.qkv_slabs + (long long)sidx * a.slab_stride + idx;
+                    const float4 p0 = *(const float4*)sp, p1 = *(const float4*)(sp + 4);
+                    v3[which][0] += p0.x; v3[which][1] += p0.y; v3[which][2] += p0.z; v3[which][3] += p0.w;
+                    v3[which][4] += p1.x; v3[which][5] += p1.y; v3[which][6] += p1.z; v3[which][7] += p1.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o);
+        const float rstd = rsqrtf((float)(ssum / (double)a.K) + a.eps);
+        if (rsel == 0) {
+#pragma unroll
+            for (int which = 0; which < 3; ++which)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v3[which][j] = bf_round(rstd * v3[which][j]);       // xqkv = wqkv(x) in bf16
+            if (a.qn_w) {
+                // q_normalization / k_normalization: LayerNorm(head_dim), eps 1e-5, computed in fp32, stored bf16
+#pragma unroll
+                for (int which = 0; which < 2; ++which) {
+                    float sm = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sm += v3[which][j];
+#pragma unroll
+                    for (int o = 1; o < LPR; o <<= 1) sm += __shfl_xor(sm, o);
+                    const float mean = sm * (1.0f / HD);
+                    float sq = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float d = v3[which][j] - mean; sq += d * d; }
+#pragma unroll
+                    for (int o = 1; o < LPR; o <<= 1) sq += __shfl_xor(sq, o);
+                    const float rs = rsqrtf(sq * (1.0f / HD) + 1e-5f);
+                    const float* gw = (which == 0 ? a.qn_w : a.kn_w) + sub * 8;
+                    const float* gb = (which == 0 ? a.qn_b : a.kn_b) + sub * 8;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v3[which][j] = bf_round((v3[which][j] - mean) * rs * gw[j] + gb[j]);
+                }
+            }
+            // rotary embedding on adjacent pairs (xformers rope_padded, adjacents=True): angle = pos * theta^(-2i/hd)
+#pragma unroll
+            for (int which = 0; which < 2; ++which)
+#pragma unroll
+                for (int p2 = 0; p2 < 4; ++p2) {
+                    const int i = sub * 4 + p2;
+                    const float freq = powf(a.theta, -2.0f * (float)i / (float)HD);
+                    float sn, cs;
+                    sincosf((float)P * freq, &sn, &cs);
+                    const float x0 = v3[which][2 * p2], x1 = v3[which][2 * p2 + 1];
+                    v3[which][2 * p2] = bf_round(x0 * cs - x1 * sn);
+                    v3[which][2 * p2 + 1] = bf_round(x0 * sn + x1 * cs);
+                }
+#pragma unroll
+            for (int which = 0; which < 3; ++which)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qkv_s[which][sub * 8 + j] = v3[which][j];
+            if (h % (a.H / a.Hkv) == 0) {
+                *(uint4*)(Kc + (long long)P * HD) = bf_pack8(v3[1]);
+                *(uint4*)(Vc + (long long)P * HD) = bf_pack8(v3[2]);
+            }
+        }
+    }
+    __syncthreads();
+    float q[8], kn[8], vn[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { q[j] = qkv_s[0][sub * 8 + j]; kn[j] = qkv_s[1][sub * 8 + j]; vn[j] = qkv_s[2][sub * 8 + j]; }
+    __builtin_amdgcn_sched_barrier(0);
+
+    float mx = -INFINITY, l = 0.f;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#define CA_CHUNK(KB_, VB_, C0)                                                            \
+    {                                                                                     \
+        float sc[CH];                                                                     \
+        float cm = -INFINITY;                                                             \
+        _Pragma("unroll") for (int u = 0; u < CH; ++u) {                                  \
+            const int t = (C0) * ROWS + u * RPI + rsel;                                   \
+            float kf[8];                                                                  \
+            bf_unpack8(KB_[u], kf);                                                       \
+            if (t >= T - 1) { _Pragma("unroll") for (int j = 0; j < 8; ++j) kf[j] = kn[j]; } \
+            float p = 0.f;                                                                \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) p += kf[j] * q[j];              \
+            _Pragma("unroll") for (int o = 1; o < LPR; o <<= 1) p += __shfl_xor(p, o);    \
+            p = (t < T) ? p * a.scale : -INFINITY;                                        \
+            sc[u] = p;                                                                    \
+            cm = fmaxf(cm, p);                                                            \
+        }                                                                                 \
+        _Pragma("unroll") for (int o = LPR; o < 64; o <<= 1) cm = fmaxf(cm, __shfl_xor(cm, o)); \
+        const float mn = fmaxf(mx, cm);                                                   \
+        const float rs = __expf(mx - mn);                                                 \
+        l *= rs;                                                                          \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[j] *= rs;                       \
+        _Pragma("unroll") for (int u = 0; u < CH; ++u) {                                  \
+            const int t = (C0) * ROWS + u * RPI + rsel;                                   \
+            float vf[8];                                                                  \
+            bf_unpack8(VB_[u], vf);                                                       \
+            if (t >= T - 1) { _Pragma("unroll") for (int j = 0; j < 8; ++j) vf[j] = vn[j]; } \
+            const float e = __expf(sc[u] - mn);                                           \
+            l += e;                                                                       \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[j] += e * vf[j];            \
+        }                                                                                 \
+        mx = mn;                                                                          \
+    }
+    for (int c = w; c < nchunk; c += 2 * NWA) {
+        if (c + NWA < nchunk) { CA_LOAD(kB, vB, c + NWA) }
+        __builtin_amdgcn_sched_barrier(0);
+        CA_CHUNK(kA, vA, c)
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 * NWA < nchunk) { CA_LOAD(kA, vA, c + 2 * NWA) }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + NWA < nchunk) { CA_CHUNK(kB, vB, c + NWA) }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef CA_LOAD
+#undef CA_CHUNK
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+        l += __shfl_xor(l, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], o);
+    }
+    if (rsel == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[w][sub * 8 + j] = acc[j];
+        if (sub == 0) { part[w][HD] = mx; part[w][HD + 1] = l; }
+    }
+    __syncthreads();
+    if (w == 0 && rsel == 0) {
+        float M = part[0][HD];
+#pragma unroll
+        for (int i = 1; i < NWA; ++i) M = fmaxf(M, part[i][HD]);
+        float L = 0.f, o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NWA; ++i) {
+            const float f = __expf(part[i][HD] - M);
+            L += part[i][HD + 1] * f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += part[i][sub * 8 + j] * f;
+        }
+        const float inv = 1.0f / L;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] *= inv;
+        const int k = h * HD + sub * 8;
+        a.y[((long long)(k >> 4) * a.MT + (m >> 5)) * 64 + (m & 31) + 32 * ((k >> 3) & 1)] = bf_pack8(o);
+    }
+}
+
+static __global__ void k_cham_set3(int* p, int a, int b, int c) { p[0] = a; p[1] = b; p[2] = c; }
+
+// per-row step bookkeeping of the generation loop
+//   mode 0: (tok, pos)[m] = table row *step of the prefill tables
+//   mode 1: tok[m] = last sampled token of image m % B (+ bpe offset already applied by the sampler), pos[m] += 1
+static __global__ void k_cham_step(long long* tok, int* pos, const long long* tab_tok, const int* tab_pos, int row, int M,
+                                   const long long* sampled, long long sampled_stride, const int* step_dev, int B, int mode) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    if (mode == 0) {
+        tok[m] = tab_tok[(long long)row * M + m];
+        pos[m] = tab_pos[(long long)row * M + m];
+    } else {
+        const int n = *step_dev;     // tokens sampled so far (>= 1)
+        tok[m] = sampled[(long long)(m % B) * sampled_stride + (n - 1)];
+        pos[m] += 1;
+    }
+}
+
+}  // namespace wmar

@@ -52,6 +52,12 @@ struct SampArgs {
     // classifier-free guidance (RAR.generate, rar.py:437-442): logits = uncond + (cond - uncond) * scale[step]
     const float* logits_uncond;  // nullable [B, V]
     const float* cfg_scale;      // device float [steps]
+    // InBatchInstructCFG (deps/chameleon/inference/logits_processor.py:312-336): with logits_img set,
+    // logits = uncond + g_image * (img - uncond) + g_text * (full - img); `logits` holds the fully conditioned rows
+    const float* logits_img;     // nullable [B, V]
+    float g_text, g_image;
+    // AllowOnlyTokensLogitsProcessor (logits_processor.py:135-156): bit v clear -> logit v = -inf (after the watermark bias)
+    const uint32_t* allow;       // nullable [V/32]
 };
 
 int launch_sample_fused(const SampArgs& a, hipStream_t st);

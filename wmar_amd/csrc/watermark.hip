@@ -134,7 +134,8 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
     const uint32_t* grow = past ? wm_row(a.wm, past, t) : nullptr;
     const float* lg = a.logits + b * V;
     const float* ul = a.logits_uncond ? a.logits_uncond + b * V : nullptr;
-    const float cfg = ul ? a.cfg_scale[step] : 0.f;
+    const float* il = a.logits_img ? a.logits_img + b * V : nullptr;
+    const float cfg = (ul && !il) ? a.cfg_scale[step] : 0.f;
     const float* q = a.q + step * a.q_step_stride + b * V;
     float* x = a.scratch + b * V;
     float* trace = a.trace ? a.trace + (step * a.B + b) * V : nullptr;
@@ -160,7 +161,11 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
         for (int i = 0; i < (EPT > 0 ? EPT : 1); ++i) {
             const long long v = tid + (long long)i * SAMP_THREADS;
             lv[i] = v < V ? lg[v] : 0.f;
-            if (ul && v < V) { const float u = ul[v]; const float dlt = lv[i] - u; const float sc = dlt * cfg; lv[i] = u + sc; }
+            if (il && v < V) {
+                const float u = ul[v], im = il[v];
+                const float d1 = im - u; const float t1 = a.g_image * d1; const float s1 = u + t1;
+                const float d2 = lv[i] - im; const float t2 = a.g_text * d2; lv[i] = s1 + t2;
+            } else if (ul && v < V) { const float u = ul[v]; const float dlt = lv[i] - u; const float sc = dlt * cfg; lv[i] = u + sc; }
         }
 #pragma unroll
         for (int i = 0; i < (EPT > 0 ? EPT : 1); ++i) {
@@ -169,6 +174,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
                 float xv = lv[i];
                 if (trace) trace[v] = xv;
                 if (grow && ((grow[v >> 5] >> (v & 31)) & 1u)) xv = xv + delta;
+                if (a.allow && !((a.allow[v >> 5] >> (v & 31)) & 1u)) xv = -INFINITY;
                 xv = xv / T;
                 x[v] = xv;
                 xr[i] = xv;
@@ -178,9 +184,14 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
     } else {
         for (long long v = tid; v < V; v += SAMP_THREADS) {
             float xv = lg[v];
-            if (ul) { const float u = ul[v]; const float dlt = xv - u; const float sc = dlt * cfg; xv = u + sc; }
+            if (il) {
+                const float u = ul[v], im = il[v];
+                const float d1 = im - u; const float t1 = a.g_image * d1; const float s1 = u + t1;
+                const float d2 = xv - im; const float t2 = a.g_text * d2; xv = s1 + t2;
+            } else if (ul) { const float u = ul[v]; const float dlt = xv - u; const float sc = dlt * cfg; xv = u + sc; }
             if (trace) trace[v] = xv;
             if (grow && ((grow[v >> 5] >> (v & 31)) & 1u)) xv = xv + delta;
+            if (a.allow && !((a.allow[v >> 5] >> (v & 31)) & 1u)) xv = -INFINITY;
             xv = xv / T;
             x[v] = xv;
             kmax = max(kmax, wmar_f32_key(xv));

@@ -4,6 +4,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import Dict, Optional
 
+import numpy as np
 import torch
 
 from .. import _lib
@@ -316,3 +317,88 @@ class MaskgitVQEngine:
                     self._h, images[b0:b1].data_ptr(), b1 - b0, codes[b0:b1].data_ptr(),
                     pre[b0 * S * S:b1 * S * S].data_ptr() if pre is not None else None, _lib.stream_ptr(self.device)))
         return (codes, pre) if return_prequant else codes
+
+
+class ChameleonEngine:
+    """Chameleon / Anole transformer decode with KV cache, three guidance streams and the fused sampler; replaces
+    ChameleonModelAdapter + Transformer.forward_with_attn_bias + the ImageDecoder token loop
+    (deps/chameleon/inference/model_adapter.py:36-119, transformer.py:288-337, chameleon.py:299-389)."""
+
+    def __init__(self, cfg, state: Dict[str, torch.Tensor], max_batch: int = 16, max_seq_len: int = 1024 + 128, device="cuda"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.max_batch = int(max_batch)
+        self.max_seq_len = int(max_seq_len)
+        L = _lib.load()
+        state = dict(state)
+        for l in range(cfg.n_layers):   # the reference's load hooks (transformer.py:84-98, 197-208)
+            p = f"layers.{l}."
+            if p + "attention.wq.weight" in state:
+                state[p + "attention.wqkv.weight"] = torch.cat([state.pop(p + "attention.wq.weight"), state.pop(p + "attention.wk.weight"),
+                                                                 state.pop(p + "attention.wv.weight")])
+            if p + "feed_forward.w1.weight" in state:
+                state[p + "feed_forward.w13.weight"] = torch.cat([state.pop(p + "feed_forward.w1.weight"),
+                                                                   state.pop(p + "feed_forward.w3.weight")])
+        state.pop("rope.freqs", None)
+        dts = {v.dtype for v in state.values()}
+        bf16 = dts == {torch.bfloat16}
+        dt = torch.bfloat16 if bf16 else torch.float32
+        tensors = {k: v.detach().to(device=self.device, dtype=dt).contiguous() for k, v in state.items()}
+        names, ptrs, n = _lib.tensor_table(tensors)
+        c = _lib.ChamConfig(cfg.dim, cfg.n_layers, cfg.n_heads, cfg.n_kv_heads, cfg.vocab_size, cfg.ffn_hidden, cfg.norm_eps,
+                            cfg.rope_theta, int(cfg.qk_normalization), int(cfg.swin_norm), 3 * self.max_batch, self.max_seq_len,
+                            int(bf16))
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(L.wmar_cham_create(C.byref(c), names, ptrs, n, _lib.stream_ptr(self.device), C.byref(h)))
+            torch.cuda.synchronize(self.device)
+        self._h = h
+        self._L = L
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.wmar_cham_destroy(h)
+            self._h = None
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self._L.wmar_cham_device_bytes(self._h))
+
+    def forward_tokens(self, tok: torch.Tensor, pos: torch.Tensor, want_logits: bool = True) -> Optional[torch.Tensor]:
+        """tok int64 [M], pos int32 [M] -> logits float32 [M, V] (one token per sequence, warm caches)."""
+        _require_cuda(tok, "tokens")
+        tok = tok.to(torch.int64).contiguous().view(-1)
+        pos = pos.to(device=self.device, dtype=torch.int32).contiguous().view(-1)
+        M = tok.shape[0]
+        logits = torch.empty(M, self.cfg.vocab_size, dtype=torch.float32, device=self.device) if want_logits else None
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.wmar_cham_forward_tokens(self._h, tok.data_ptr(), pos.data_ptr(), M,
+                                                        logits.data_ptr() if want_logits else None, _lib.stream_ptr(self.device)))
+        return logits
+
+    def generate_image(self, prompts, q: torch.Tensor, n_tokens: int, temperature: float, top_p: Optional[float],
+                       guidance_scale_text: float, guidance_scale_image: float, allow: Optional[torch.Tensor] = None,
+                       wm_ctx: Optional[_lib.WmCtx] = None, use_graph: bool = True) -> torch.Tensor:
+        """prompts: the 3B token lists (full-, image-, un-conditioned, in that order); q float32 [n_tokens, B, V];
+        allow: int32 bitmap [V/32] of permitted vocabulary entries.  Returns int64 [B, n_tokens] vocabulary ids."""
+        _require_cuda(q, "q")
+        M = len(prompts)
+        assert M % 3 == 0
+        B = M // 3
+        V = self.cfg.vocab_size
+        assert q.shape == (n_tokens, B, V) and q.dtype == torch.float32 and q.is_contiguous()
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.int64) for p in prompts]))
+        lens = np.ascontiguousarray(np.asarray([len(p) for p in prompts], dtype=np.int32))
+        out = torch.empty(B, n_tokens, dtype=torch.int64, device=self.device)
+        sp = _lib.ChamSampleParams(float(temperature), float(top_p) if top_p is not None else -1.0, float(guidance_scale_text),
+                                   float(guidance_scale_image), 1 if use_graph else 0)
+        if allow is not None:
+            _require_cuda(allow, "allow bitmap")
+            assert allow.dtype == torch.int32 and allow.numel() == V // 32 and allow.is_contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.wmar_cham_generate_image(
+                self._h, C.byref(wm_ctx) if wm_ctx is not None else None, flat.ctypes.data, lens.ctypes.data, B, C.byref(sp),
+                allow.data_ptr() if allow is not None else None, q.data_ptr(), int(n_tokens), out.data_ptr(),
+                _lib.stream_ptr(self.device)))
+        return out

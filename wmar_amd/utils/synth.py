@@ -432,3 +432,78 @@ def synth_maskgit_state(cfg: MaskgitVQConfig, seed: int = 0, device="cpu", gen_d
             t = (torch.rand(shp, generator=g, device=gen_device) * 2.0 - 1.0) * (3.0 / fan_in) ** 0.5
         out[k] = t.to(torch.float32).to(device)
     return out
+
+
+# ----------------------------------------------------------------------------- Chameleon
+@dataclasses.dataclass
+class ChameleonConfig:
+    """deps/chameleon/inference/transformer.py:18-31 (ModelArgs).  Defaults: the 7B model (Anole-7B)."""
+    dim: int = 4096
+    n_layers: int = 32
+    n_heads: int = 32
+    n_kv_heads: int = 32
+    vocab_size: int = 65536
+    ffn_dim_multiplier: float = 1.0
+    multiple_of: int = 256
+    norm_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    qk_normalization: bool = True
+    swin_norm: bool = False
+
+    @property
+    def head_dim(self) -> int:
+        return self.dim // self.n_heads
+
+    @property
+    def ffn_hidden(self) -> int:
+        """FeedForward.__init__, transformer.py:175-179."""
+        hidden = int(2 * (4 * self.dim) / 3)
+        if self.ffn_dim_multiplier is not None:
+            hidden = int(self.ffn_dim_multiplier * hidden)
+        return self.multiple_of * ((hidden + self.multiple_of - 1) // self.multiple_of)
+
+
+CHAMELEON_7B = ChameleonConfig()
+
+
+def chameleon_shapes(cfg: ChameleonConfig) -> Dict[str, Tuple[int, ...]]:
+    """Key names of the consolidated checkpoint after the wq/wk/wv -> wqkv and w1/w3 -> w13 load hooks
+    (transformer.py:84-98, 197-208)."""
+    hd, D, F = cfg.head_dim, cfg.dim, cfg.ffn_hidden
+    s: Dict[str, Tuple[int, ...]] = {"tok_embeddings.weight": (cfg.vocab_size, D), "norm.weight": (D,),
+                                    "output.weight": (cfg.vocab_size, D)}
+    for l in range(cfg.n_layers):
+        p = f"layers.{l}."
+        s[p + "attention.wqkv.weight"] = ((cfg.n_heads + 2 * cfg.n_kv_heads) * hd, D)
+        s[p + "attention.wo.weight"] = (D, cfg.n_heads * hd)
+        if cfg.qk_normalization:
+            for n in ("q_normalization", "k_normalization"):
+                s[p + f"attention.{n}.weight"] = (hd,)
+                s[p + f"attention.{n}.bias"] = (hd,)
+        s[p + "feed_forward.w13.weight"] = (2 * F, D)
+        s[p + "feed_forward.w2.weight"] = (D, F)
+        s[p + "attention_norm.weight"] = (D,)
+        s[p + "ffn_norm.weight"] = (D,)
+    return s
+
+
+def synth_chameleon_state(cfg: ChameleonConfig, seed: int = 0, device="cpu", logit_scale: float = 1.0, gen_device="cpu",
+                          dtype=torch.bfloat16):
+    """Random checkpoint in the reference's storage dtype (bf16)."""
+    g = torch.Generator(device=gen_device)
+    g.manual_seed(seed + 7007)
+    out = {}
+    for k, shp in chameleon_shapes(cfg).items():
+        if k.endswith("norm.weight") or k.endswith("normalization.weight"):
+            t = 1.0 + 0.1 * torch.randn(shp, generator=g, device=gen_device)
+        elif k.endswith("normalization.bias"):
+            t = 0.05 * torch.randn(shp, generator=g, device=gen_device)
+        elif k == "tok_embeddings.weight":
+            t = torch.randn(shp, generator=g, device=gen_device, dtype=torch.bfloat16 if len(shp) == 2 and shp[0] * shp[1] > 1 << 26 else torch.float32)
+        elif k == "output.weight":
+            t = torch.randn(shp, generator=g, device=gen_device, dtype=torch.bfloat16 if shp[0] * shp[1] > 1 << 26 else torch.float32) * (logit_scale / shp[1] ** 0.5)
+        else:
+            big = shp[0] * shp[1] > 1 << 26
+            t = torch.randn(shp, generator=g, device=gen_device, dtype=torch.bfloat16 if big else torch.float32) * (1.0 / shp[1] ** 0.5)
+        out[k] = t.to(dtype).to(device)
+    return out
