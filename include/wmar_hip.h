@@ -291,6 +291,17 @@ int wmar_cham_generate_image(wmar_cham* g, const wmar_wm_ctx* wm, const int64_t*
                              const uint32_t* allow_dev, const float* q_dev, int32_t n_tokens, int64_t* tokens_out_dev,
                              void* stream);
 
+/* The ImageDecoder logits pipeline of one step as ONE launch (chameleon.py:313-327, generation.py:84-93):
+ * logits3_dev float [3B, V] = [full | image-conditioned | unconditioned] rows; guidance mix
+ * (logits_processor.py:312-336) -> watermark bias (called positionally on the input rows,
+ * past_ids_dev int64 [B, past_stride] with t valid entries; nullable for FIXED keys) ->
+ * allow-only bitmap (nullable) -> /temperature -> top-p (< 0: off) -> softmax ->
+ * argmax(p / q) on the first stream (token_selector.py:36-47).  tok_out_dev int64 [B]. */
+int wmar_cham_sample(const wmar_wm_ctx* wm, const float* logits3_dev, int64_t B, int64_t V, const int64_t* past_ids_dev,
+                     int64_t t, int64_t past_stride, float temperature, double top_p, float guidance_scale_text,
+                     float guidance_scale_image, const uint32_t* allow_dev, const float* q_dev, float* scratch_dev,
+                     int64_t* tok_out_dev, void* stream);
+
 /* ---------------------------------------------------------------------- VQGAN
  * Taming VQGAN (deps/taming/models/vqgan.py:30-73, modules/diffusionmodules/model.py:343-538,
  * modules/vqvae/quantize.py:272-331).  Tensors by key name relative to `first_stage_model.`

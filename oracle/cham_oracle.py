@@ -140,3 +140,23 @@ def instruct_cfg(logits: T, g_text: float, g_image: float) -> T:
     """InBatchInstructCFGLogitsProcessor (logits_processor.py:312-336) on [3B, V] -> mixed [B, V]."""
     full, img, unc = logits.chunk(3)
     return unc + g_image * (img - unc) + g_text * (full - img)
+
+
+def sample_step(logits3: T, q: T, temperature: float, top_p: Optional[float], g_text: float, g_image: float,
+                allow_ids=None, key=None, past_ids=None, delta: float = 0.0):
+    """One ImageDecoder step after the model (chameleon.py:313-327, generation.py:84-93): guidance mix -> watermark (called
+    positionally on the first stream's input rows) -> allow-only -> temperature -> top-p -> softmax -> multinomial on the
+    first stream.  Returns (tokens int64 [B], processed logits [B, V] before temperature)."""
+    import numpy as np
+
+    from oracle import wm_oracle as W
+    B = logits3.shape[0] // 3
+    lg = instruct_cfg(logits3.float(), g_text, g_image).numpy().copy()
+    if key is not None:
+        lg = W.process_logits(key, np.asarray(past_ids)[:B], lg, delta)
+    if allow_ids is not None:
+        keep = np.zeros(lg.shape[1], dtype=bool)
+        keep[np.asarray(allow_ids)] = True
+        lg[:, ~keep] = -np.inf
+    tok = W.sample_rows(lg, np.asarray(q, dtype=np.float32), temperature, None, top_p)
+    return tok, lg

@@ -140,6 +140,87 @@ def rar_vectors(args, synth, wms, rs):
     print("wrote rar_vectors.npz", os.path.getsize(os.path.join(HERE, "rar_vectors.npz")), "bytes")
 
 
+def synth_vocab_map(n_vocab=2048, n_img=512, first_img=4):
+    """A Chameleon-style vocabulary (tokenizer json: name -> id): specials, IMGIMG<letters>Z image tokens (vocab.py:77-93), text."""
+    vm = {"<pad>": 1, "<s>": 0, "</s>": 2, "<reserved08706>": 3}
+    digits = "ABCDEFGHIJ"
+    nxt = first_img
+    for code in range(n_img):
+        vm["IMGIMG" + "".join(digits[int(c)] for c in str(code)) + "Z"] = nxt
+        nxt += 1
+    vm["<racm3:break>"] = nxt
+    vm["<eoss>"] = nxt + 1
+    nxt += 2
+    i = 0
+    while nxt < n_vocab:
+        vm[f"t{i}"] = nxt
+        nxt += 1
+        i += 1
+    return vm
+
+
+def chameleon_vectors(args):
+    """Known answers of the importable Chameleon host pieces: logits processors (logits_processor.py:135-156, 312-336),
+    HF temperature / top-p warpers as chameleon.py:313-327 chains them, MultinomialTokenSelector / ReplicatedInputTokenSelector
+    (token_selector.py:26-47), VocabInfo / VocabTranslation (vocab.py), the GentimeWatermark positional call."""
+    import torch
+    from transformers import LogitsProcessorList, TemperatureLogitsWarper, TopPLogitsWarper
+    from deps.chameleon.inference.logits_processor import AllowOnlyTokensLogitsProcessor, InBatchInstructCFGLogitsProcessor
+    from deps.chameleon.inference.token_selector import MultinomialTokenSelector, ReplicatedInputTokenSelector
+    from deps.chameleon.inference.vocab import VocabInfo, VocabTranslation
+    from wmar.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
+
+    out = {}
+    vm = synth_vocab_map()
+    V = len(vm)
+    vi = VocabInfo(vm)
+    vt = VocabTranslation(vi)
+    out["cham_image_tokens"] = np.array(vi.image_tokens, dtype=np.int64)
+    out["cham_text_tokens"] = np.array(vi.text_tokens, dtype=np.int64)
+    out["cham_special_tokens"] = np.array(vi.special_tokens, dtype=np.int64)
+    out["cham_ids"] = np.array([vi.bos_id, vi.eos_id, vi.boi_id, vi.eoi_id, vi.pad_id, vi.eot_id], dtype=np.int64)
+    bpe = torch.tensor([[4, 5, 515, 100], [300, 4, 4, 17]])
+    out["cham_bpe_batch"] = bpe.numpy()
+    out["cham_bpe2img"] = vt.convert_bpe2img(bpe).numpy()
+    img = torch.tensor([[0, 511, 9], [10, 99, 100]])
+    out["cham_img_batch"] = img.numpy()
+    out["cham_img2bpe"] = vt.convert_img2bp2(img).numpy().astype(np.int64)
+
+    B = 5
+    g = torch.Generator().manual_seed(77)
+    logits = (torch.randn(3 * B, V, generator=g) * 2.5).bfloat16().float()      # bf16-valued like the model's output
+    out["cham_logits3"] = logits.numpy()
+    alive = vi.image_tokens
+    dead = sorted(set(range(V)) - set(alive))
+    vq = {"alive_ids": torch.tensor(alive), "dead_ids": torch.tensor(dead), "embedding": torch.zeros(V, 4)}
+    input_ids = torch.randint(0, V, (3 * B, 7), generator=g)
+    input_ids[:, -1] = vi.boi_id
+    out["cham_input_ids"] = input_ids.numpy()
+    for name, seed_s, h, delta, temp, top_p in [("fixed", SeedStrategy.FIXED, 0, 2.0, 1.0, 0.9),
+                                                ("linear", SeedStrategy.LINEAR, 1, 4.0, 0.7, 0.5),
+                                                ("nowm", None, 0, 0.0, 1.0, 0.9)]:
+        procs = [InBatchInstructCFGLogitsProcessor(3.0, 1.2)]
+        if seed_s is not None:
+            wm = GentimeWatermark(vq, V, seed_s, SplitStrategy.RANDOM_STRATIFIED, h, delta, 0.25, device="cpu")
+            procs.append(wm.spawn_logit_processor())
+        procs += [AllowOnlyTokensLogitsProcessor(vi.image_tokens), TemperatureLogitsWarper(temp), TopPLogitsWarper(top_p)]
+        lp = LogitsProcessorList(procs)
+        lg = lp(input_ids, logits.clone())
+        probs = lg.softmax(dim=1)
+        sel = ReplicatedInputTokenSelector(MultinomialTokenSelector(), n=3)
+        torch.manual_seed(1234)
+        tok = sel(input_ids, probs)
+        torch.manual_seed(1234)
+        q = torch.empty(B, V).exponential_(1)
+        assert torch.equal(tok[:B], (probs[:B] / q).argmax(dim=1)) and torch.equal(tok, tok[:B].repeat(3))
+        out[f"cham_{name}_processed"] = lg[:B].numpy()
+        out[f"cham_{name}_tok"] = tok[:B].numpy().astype(np.int64)
+        out[f"cham_{name}_q"] = q.numpy()
+        out[f"cham_{name}_params"] = np.array([h, delta, temp, top_p], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "chameleon_vectors.npz"), **out)
+    print("wrote chameleon_vectors.npz", os.path.getsize(os.path.join(HERE, "chameleon_vectors.npz")), "bytes")
+
+
 def gumbel_vectors(args):
     """Known answers of wmar_audio/watermark/engine.py (gumbel_sample, gumbel_score_tok, get_wm_window_hash)."""
     import torch
@@ -181,10 +262,17 @@ def gumbel_vectors(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--only", default="", help="'gumbel': regenerate gumbel_vectors.npz only")
+    ap.add_argument("--only", default="", help="'gumbel' / 'chameleon': regenerate only that fixture file")
     args = ap.parse_args()
     if args.only == "gumbel":
         gumbel_vectors(args)
+        return
+    if args.only == "chameleon":
+        tmp = tempfile.mkdtemp(prefix="wmar_stubs_")
+        _stubs(tmp)
+        sys.path[:0] = [tmp, args.ref, REPO]
+        os.chdir(args.ref)
+        chameleon_vectors(args)
         return
     tmp = tempfile.mkdtemp(prefix="wmar_stubs_")
     _stubs(tmp)
@@ -408,6 +496,7 @@ def main():
 
     rar_vectors(args, synth, wms, rs)
     gumbel_vectors(args)
+    chameleon_vectors(args)
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     sz = os.path.getsize(os.path.join(HERE, "reference_vectors.npz"))
     print("wrote reference_vectors.npz", sz, "bytes; key_kat.json")

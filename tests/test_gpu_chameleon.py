@@ -66,3 +66,93 @@ def test_ragged_positions_and_cache_rewrite():
     got2 = e.forward_tokens(tok.cuda(), nxt.to(torch.int32).cuda()).cpu()
     ref2 = CO.forward_tokens(sd, cfg, tok, nxt, cache, fold=True)
     _close(got2, ref2, 0.03)
+
+
+@pytest.fixture(scope="module")
+def cv():
+    import os
+    from tests.conftest import REPO
+    return np.load(os.path.join(REPO, "tests", "golden", "chameleon_vectors.npz"))
+
+
+@pytest.mark.parametrize("name,seed", [("fixed", "fixed"), ("linear", "linear"), ("nowm", None)])
+def test_cham_sample_reference_tokens(cv, name, seed):
+    """guidance mix -> watermark -> allow-only -> temperature -> top-p -> multinomial in ONE launch reproduces the reference's tokens."""
+    import ctypes as C
+    from wmar_amd import _lib
+    from wmar_amd.models.chameleon_wrapper import allow_bitmap
+    from wmar_amd.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
+    h, delta, temp, top_p = cv[f"cham_{name}_params"]
+    lg = torch.from_numpy(cv["cham_logits3"]).cuda()
+    B, V = lg.shape[0] // 3, lg.shape[1]
+    alive = cv["cham_image_tokens"]
+    dead = sorted(set(range(V)) - set(alive.tolist()))
+    ctx = None
+    if seed:
+        vq = {"alive_ids": torch.tensor(alive), "dead_ids": torch.tensor(dead), "embedding": torch.zeros(V, 4)}
+        wm = GentimeWatermark(vq, V, SeedStrategy(seed), SplitStrategy.RANDOM_STRATIFIED, int(h), float(delta), 0.25, device="cuda")
+        ctx = wm.wm_ctx()
+    past = torch.from_numpy(cv["cham_input_ids"][:B]).cuda().contiguous()
+    q = torch.from_numpy(cv[f"cham_{name}_q"]).cuda()
+    out = torch.empty(B, dtype=torch.int64, device="cuda")
+    scratch = torch.empty(B, V, device="cuda")
+    allow = allow_bitmap(alive.tolist(), V, "cuda")
+    _lib.check(_lib.load().wmar_cham_sample(C.byref(ctx) if ctx is not None else None, lg.data_ptr(), B, V, past.data_ptr(), past.shape[1],
+                                            past.stride(0), float(temp), float(top_p), 3.0, 1.2, allow.data_ptr(), q.data_ptr(),
+                                            scratch.data_ptr(), out.data_ptr(), _lib.stream_ptr()))
+    assert np.array_equal(out.cpu().numpy(), cv[f"cham_{name}_tok"])
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_generate_image_loop(graph):
+    """The captured generation loop: every sampled token equals the oracle's sampling chain applied to the engine's own
+    step logits (same prompts, same tokens fed back), with ragged prompts, a LINEAR watermark and top-p."""
+    from wmar_amd.models.chameleon_wrapper import ChameleonARMMWrapper
+    from wmar_amd.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
+    from oracle import wm_oracle as W
+    cfg = _cfg(hd=64, dim=256, vocab=2048)
+    vq_cfg = synth.VQConfig(ch=32, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(), resolution=16, z_channels=32, embed_dim=32,
+                            n_embed=512)
+    sd = synth.synth_chameleon_state(cfg, seed=8, logit_scale=6.0)
+    vm = synth.synth_chameleon_vocab(2048, 512)
+    m = ChameleonARMMWrapper(None, 0, cfg=cfg, state=sd, vocab_map=vm, vq_cfg=vq_cfg, vq_state=synth.synth_vq_state(vq_cfg, 1),
+                             max_batch=3, max_prompt_len=16)
+    assert m.n_image_tokens == 64
+    m.use_graph = graph
+    wm = GentimeWatermark(m.get_vq(), 2048, SeedStrategy.LINEAR, SplitStrategy.RANDOM_STRATIFIED, 1, 3.0, 0.25, device="cuda")
+    m.set_watermarker(wm)
+    text = m.vocab.text_tokens
+    cond = [(0, [text[5], text[9], text[100]]), (1, [text[7]]), (2, [text[1], text[2], text[3], text[4], text[400]])]
+    torch.manual_seed(3)
+    q = m.draw_noise(3)
+    codes = m.sample(cond, {"temperature": 0.9, "top_p": 0.8}, apply_watermark=True, q=q)
+    assert set(codes.flatten().tolist()) <= set(m.vocab.image_tokens)
+    # replay on a second engine, step by step
+    from wmar_amd.models.engine import ChameleonEngine
+    e2 = ChameleonEngine(cfg, sd, max_batch=3, max_seq_len=16 + 64)
+    prompts = m.split_inputs_for_cfg([m.tokens_from_ui([{"type": "ids", "value": p}, {"type": "sentinel", "value": "<END-OF-TURN>"}])
+                                      for _, p in cond])
+    M, maxlen = len(prompts), max(len(p) for p in prompts)
+    lg = None
+    for j in range(maxlen):
+        tok = [p[j - (maxlen - len(p))] if j - (maxlen - len(p)) >= 0 else 0 for p in prompts]
+        pos = [max(j - (maxlen - len(p)), 0) for p in prompts]
+        lg = e2.forward_tokens(torch.tensor(tok).cuda(), torch.tensor(pos, dtype=torch.int32).cuda())
+    key = W.KeyParams(wm._alive_host, wm._dead_host, 2048, 0.25, seed="linear")
+    past = np.array([[p[-1]] for p in prompts[:3]], dtype=np.int64)
+    pos = torch.tensor([len(p) for p in prompts], dtype=torch.int32)
+    for n in range(64):
+        tok, _ = CO.sample_step(lg.cpu(), q[n].cpu().numpy(), 0.9, 0.8, 3.0, 1.2, allow_ids=m.vocab.image_tokens, key=key, past_ids=past,
+                                delta=3.0)
+        assert np.array_equal(tok, codes[:, n].cpu().numpy()), n
+        past = np.concatenate([past, tok[:, None]], axis=1)
+        if n < 63:
+            t3 = torch.from_numpy(np.concatenate([tok, tok, tok]))
+            lg = e2.forward_tokens(t3.cuda(), (pos + n).cuda())
+    # decode -> re-encode -> detect through the wrapper
+    imgs = m.codes_to_images(codes)
+    assert imgs.shape == (3, 3, 16, 16)
+    c2 = m.images_to_codes(imgs)
+    assert c2.shape == codes.shape and set(c2.flatten().tolist()) <= set(m.vocab.image_tokens)
+    pv = wm.detect(codes)
+    assert float(pv.median()) < 5e-2      # 64 tokens only: the watermark is visible, not overwhelming

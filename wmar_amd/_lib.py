@@ -22,6 +22,7 @@ SYMBOLS = [
     "wmar_vq_decode", "wmar_vq_encode", "wmar_mvq_create", "wmar_mvq_destroy", "wmar_mvq_device_bytes", "wmar_mvq_decode",
     "wmar_mvq_encode", "wmar_gumbel_key_build", "wmar_gumbel_sample", "wmar_gumbel_score", "wmar_rar_generate_gumbel",
     "wmar_cham_create", "wmar_cham_destroy", "wmar_cham_device_bytes", "wmar_cham_forward_tokens", "wmar_cham_generate_image",
+    "wmar_cham_sample",
 ]
 
 WMAR_ESHORT = -3
@@ -152,6 +153,7 @@ def load():
     L.wmar_cham_device_bytes.argtypes = [vp]
     L.wmar_cham_forward_tokens.argtypes = [vp, vp, vp, i64, vp, vp]
     L.wmar_cham_generate_image.argtypes = [vp, C.POINTER(WmCtx), vp, vp, i64, C.POINTER(ChamSampleParams), vp, vp, i32, vp, vp]
+    L.wmar_cham_sample.argtypes = [C.POINTER(WmCtx), vp, i64, i64, vp, i64, i64, f32, f64, f32, f32, vp, vp, vp, vp, vp]
     L.wmar_mvq_create.argtypes = [C.POINTER(MvqConfig), C.POINTER(C.c_char_p), C.POINTER(vp), i32, vp, C.POINTER(vp)]
     L.wmar_mvq_destroy.argtypes = [vp]
     L.wmar_mvq_destroy.restype = None

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
     const long long t = a.t_dev ? (long long)*a.t_dev : a.t_host;
     const long long step = a.step_dev ? (long long)*a.step_dev : 0;
     const long long* past = a.past ? a.past + b * a.past_stride : nullptr;
-    const uint32_t* grow = past ? wm_row(a.wm, past, t) : nullptr;
+    const uint32_t* grow = (past || a.wm.seed_mode == WMAR_SEED_FIXED) ? wm_row(a.wm, past, t) : nullptr;
     const float* lg = a.logits + b * V;
     const float* ul = a.logits_uncond ? a.logits_uncond + b * V : nullptr;
     const float* il = a.logits_img ? a.logits_img + b * V : nullptr;
@@ -548,6 +548,42 @@ int wmar_sample_fused(const wmar_wm_ctx* wm, const float* logits_dev, int64_t B,
     a.t_host = t;
     a.temperature = temperature;
     a.top_k = top_k;
+    a.use_top_p = top_p >= 0;
+    a.top_p_thr = (float)(1.0 - top_p);
+    a.q = q_dev;
+    a.scratch = scratch_dev;
+    a.tok_out = (long long*)tok_out_dev;
+    a.tok_out_stride = 1;
+    a.B = B;
+    return launch_sample_fused(a, (hipStream_t)stream);
+}
+
+int wmar_cham_sample(const wmar_wm_ctx* wm, const float* logits3_dev, int64_t B, int64_t V, const int64_t* past_ids_dev,
+                     int64_t t, int64_t past_stride, float temperature, double top_p, float guidance_scale_text,
+                     float guidance_scale_image, const uint32_t* allow_dev, const float* q_dev, float* scratch_dev,
+                     int64_t* tok_out_dev, void* stream) {
+    WMAR_REQUIRE(logits3_dev && q_dev && scratch_dev && tok_out_dev, "cham_sample: null argument");
+    WMAR_REQUIRE(V > 0 && V < (1ll << 31), "cham_sample: bad vocab");
+    WMAR_REQUIRE(!(top_p >= 0) || top_p <= 1.0, "`top_p` has to be a float > 0 and < 1, but is %f", top_p);
+    if (wm) {
+        if (int rc = check_wm(wm, V)) return rc;
+        WMAR_REQUIRE(past_ids_dev || wm->seed_strategy == WMAR_SEED_FIXED, "cham_sample: past_ids required");
+    }
+    if (B == 0) return WMAR_OK;
+    SampArgs a{};
+    a.wm = make_wm(wm);
+    a.logits = logits3_dev;
+    a.logits_img = logits3_dev + B * V;
+    a.logits_uncond = logits3_dev + 2 * B * V;
+    a.g_text = guidance_scale_text;
+    a.g_image = guidance_scale_image;
+    a.allow = allow_dev;
+    a.V = V;
+    a.past = (const long long*)past_ids_dev;
+    a.past_stride = past_stride;
+    a.t_host = t;
+    a.temperature = temperature;
+    a.top_k = 0;
     a.use_top_p = top_p >= 0;
     a.top_p_thr = (float)(1.0 - top_p);
     a.q = q_dev;

@@ -507,3 +507,26 @@ def synth_chameleon_state(cfg: ChameleonConfig, seed: int = 0, device="cpu", log
             t = torch.randn(shp, generator=g, device=gen_device, dtype=torch.bfloat16 if big else torch.float32) * (1.0 / shp[1] ** 0.5)
         out[k] = t.to(dtype).to(device)
     return out
+
+
+CHAMELEON_VQ = VQConfig(ch=128, ch_mult=(1, 1, 2, 2, 4), num_res_blocks=2, attn_resolutions=(), resolution=512, z_channels=256,
+                        embed_dim=256, n_embed=8192)   # assets/chameleon_patched_config.yaml
+
+
+def synth_chameleon_vocab(n_vocab: int = 65536, n_img: int = 8192, first_img: int = 4) -> Dict[str, int]:
+    """A Chameleon-style tokenizer vocabulary (name -> id): specials, ``IMGIMG<letters>Z`` image tokens whose letters A..J
+    spell the VQGAN code (vocab.py:82-93), filler text tokens."""
+    vm = {"<s>": 0, "<pad>": 1, "</s>": 2, "<reserved08706>": 3}
+    nxt = first_img
+    for code in range(n_img):
+        vm["IMGIMG" + "".join("ABCDEFGHIJ"[int(c)] for c in str(code)) + "Z"] = nxt
+        nxt += 1
+    vm["<racm3:break>"] = nxt
+    vm["<eoss>"] = nxt + 1
+    nxt += 2
+    i = 0
+    while nxt < n_vocab:
+        vm[f"t{i}"] = nxt
+        nxt += 1
+        i += 1
+    return vm
