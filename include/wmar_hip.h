@@ -282,25 +282,27 @@ int wmar_cham_forward_tokens(wmar_cham* g, const int64_t* tok_dev, const int32_t
 /* ImageDecoder (chameleon.py:299-389) for B prompts: prompt_tokens_host = the 3B token lists of
  * _split_inputs_for_cfg (:351-372; full-conditioned, image-conditioned, unconditioned) laid end to
  * end, prompt_lens_host int32 [3B].  Per generated token: guidance mix -> watermark bias ->
- * allow-only (allow_dev: bit per vocabulary entry, nullable) -> temperature -> top-p -> softmax ->
+ * allow-only (allow_dev: bit per vocabulary entry, nullable; allow_ids_dev: the same set as ascending int32 ids
+ * [n_allow], nullable -- with it the sampler works on the compacted row, which is exact) -> temperature -> top-p -> softmax ->
  * multinomial on the first stream (q_dev float [n_tokens, B, vocab] Exp(1) noise, one [B, vocab]
  * draw per token as probs.multinomial makes).  tokens_out_dev int64 [B, n_tokens] (vocabulary ids).
  * The watermark context is the sequence so far (last prompt token first). */
 int wmar_cham_generate_image(wmar_cham* g, const wmar_wm_ctx* wm, const int64_t* prompt_tokens_host,
                              const int32_t* prompt_lens_host, int64_t B, const wmar_cham_sample_params* sp,
-                             const uint32_t* allow_dev, const float* q_dev, int32_t n_tokens, int64_t* tokens_out_dev,
-                             void* stream);
+                             const uint32_t* allow_dev, const int32_t* allow_ids_dev, int32_t n_allow, const float* q_dev,
+                             int32_t n_tokens, int64_t* tokens_out_dev, void* stream);
 
 /* The ImageDecoder logits pipeline of one step as ONE launch (chameleon.py:313-327, generation.py:84-93):
  * logits3_dev float [3B, V] = [full | image-conditioned | unconditioned] rows; guidance mix
  * (logits_processor.py:312-336) -> watermark bias (called positionally on the input rows,
  * past_ids_dev int64 [B, past_stride] with t valid entries; nullable for FIXED keys) ->
- * allow-only bitmap (nullable) -> /temperature -> top-p (< 0: off) -> softmax ->
+ * allow-only bitmap (nullable; allow_ids_dev / n_allow: the same set as ascending ids, enables row compaction) ->
+ * /temperature -> top-p (< 0: off) -> softmax ->
  * argmax(p / q) on the first stream (token_selector.py:36-47).  tok_out_dev int64 [B]. */
 int wmar_cham_sample(const wmar_wm_ctx* wm, const float* logits3_dev, int64_t B, int64_t V, const int64_t* past_ids_dev,
                      int64_t t, int64_t past_stride, float temperature, double top_p, float guidance_scale_text,
-                     float guidance_scale_image, const uint32_t* allow_dev, const float* q_dev, float* scratch_dev,
-                     int64_t* tok_out_dev, void* stream);
+                     float guidance_scale_image, const uint32_t* allow_dev, const int32_t* allow_ids_dev, int32_t n_allow,
+                     const float* q_dev, float* scratch_dev, int64_t* tok_out_dev, void* stream);
 
 /* ---------------------------------------------------------------------- VQGAN
  * Taming VQGAN (deps/taming/models/vqgan.py:30-73, modules/diffusionmodules/model.py:343-538,

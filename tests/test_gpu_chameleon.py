@@ -75,8 +75,9 @@ def cv():
     return np.load(os.path.join(REPO, "tests", "golden", "chameleon_vectors.npz"))
 
 
+@pytest.mark.parametrize("compact", [False, True])
 @pytest.mark.parametrize("name,seed", [("fixed", "fixed"), ("linear", "linear"), ("nowm", None)])
-def test_cham_sample_reference_tokens(cv, name, seed):
+def test_cham_sample_reference_tokens(cv, name, seed, compact):
     """guidance mix -> watermark -> allow-only -> temperature -> top-p -> multinomial in ONE launch reproduces the reference's tokens."""
     import ctypes as C
     from wmar_amd import _lib
@@ -97,8 +98,10 @@ def test_cham_sample_reference_tokens(cv, name, seed):
     out = torch.empty(B, dtype=torch.int64, device="cuda")
     scratch = torch.empty(B, V, device="cuda")
     allow = allow_bitmap(alive.tolist(), V, "cuda")
+    ids = torch.from_numpy(np.sort(alive).astype(np.int32)).cuda()
     _lib.check(_lib.load().wmar_cham_sample(C.byref(ctx) if ctx is not None else None, lg.data_ptr(), B, V, past.data_ptr(), past.shape[1],
-                                            past.stride(0), float(temp), float(top_p), 3.0, 1.2, allow.data_ptr(), q.data_ptr(),
+                                            past.stride(0), float(temp), float(top_p), 3.0, 1.2, allow.data_ptr(),
+                                            ids.data_ptr() if compact else None, ids.numel() if compact else 0, q.data_ptr(),
                                             scratch.data_ptr(), out.data_ptr(), _lib.stream_ptr()))
     assert np.array_equal(out.cpu().numpy(), cv[f"cham_{name}_tok"])
 

@@ -152,8 +152,8 @@ def load():
     L.wmar_cham_device_bytes.restype = i64
     L.wmar_cham_device_bytes.argtypes = [vp]
     L.wmar_cham_forward_tokens.argtypes = [vp, vp, vp, i64, vp, vp]
-    L.wmar_cham_generate_image.argtypes = [vp, C.POINTER(WmCtx), vp, vp, i64, C.POINTER(ChamSampleParams), vp, vp, i32, vp, vp]
-    L.wmar_cham_sample.argtypes = [C.POINTER(WmCtx), vp, i64, i64, vp, i64, i64, f32, f64, f32, f32, vp, vp, vp, vp, vp]
+    L.wmar_cham_generate_image.argtypes = [vp, C.POINTER(WmCtx), vp, vp, i64, C.POINTER(ChamSampleParams), vp, vp, i32, vp, i32, vp, vp]
+    L.wmar_cham_sample.argtypes = [C.POINTER(WmCtx), vp, i64, i64, vp, i64, i64, f32, f64, f32, f32, vp, vp, i32, vp, vp, vp, vp]
     L.wmar_mvq_create.argtypes = [C.POINTER(MvqConfig), C.POINTER(C.c_char_p), C.POINTER(vp), i32, vp, C.POINTER(vp)]
     L.wmar_mvq_destroy.argtypes = [vp]
     L.wmar_mvq_destroy.restype = None

@@ -12,6 +12,7 @@
 // token by token through the same captured step (prompts are a few dozen tokens against 1024
 // generated ones), rows of shorter prompts idle until their turn (AlignPromptRight).
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -39,10 +40,11 @@ struct wmar_cham {
     uint4* whead = nullptr;
     // workspaces
     uint4 *x = nullptr, *y = nullptr, *hbuf = nullptr;
-    float *slabs = nullptr, *qkv_slabs = nullptr, *logits = nullptr, *scratch = nullptr;
+    float *slabs = nullptr, *big_slabs = nullptr, *logits = nullptr, *scratch = nullptr;   // pieces of D-wide / of QKV and w13 outputs
     double* ssq = nullptr;
     uint16_t *kcache = nullptr, *vcache = nullptr;
     long long *tok = nullptr, *ids = nullptr;
+    float2* rope = nullptr;
     int *pos = nullptr, *ctr = nullptr;     // ctr: [unused, step, len]
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev = nullptr;
@@ -66,34 +68,53 @@ struct wmar_cham {
 
 namespace {
 
-constexpr int CHAM_MAX_SLABS = 8;
+// workgroups of the stream-K GEMM: one per CU (measured: 256 -> 5.3 ms/step, 512 -> 5.9, 1024 -> 6.5 on the 7B model; the kernel
+// runs at one wave per SIMD, so more workgroups only add pieces and prologues); WMAR_CHAM_GRID overrides
+int cham_grid() {
+    static int g = 0;
+    if (!g) {
+        const char* e = getenv("WMAR_CHAM_GRID");
+        g = e ? atoi(e) : 256;
+        if (g < 1) g = 256;
+    }
+    return g;
+}
+
+SkInfo sk_for(int NT, int KB, bool whole_groups) {
+    SkInfo k;
+    const int groups = (NT + BG_TG - 1) / BG_TG;
+    k.C = (KB + BG_KC - 1) / BG_KC;
+    k.U = groups * k.C;
+    const int target = cham_grid();
+    if (whole_groups) {
+        // every workgroup owns whole groups: the largest grid <= target that divides the group count
+        int per = (groups + target - 1) / target;
+        while (groups % per) ++per;
+        k.G = groups / per;
+    } else {
+        // at most BG_MAXP pieces per group (the slab buffers are sized for that)
+        auto max_pieces = [&](int G) {
+            SkInfo t = k;
+            t.G = G;
+            int mx = 0;
+            for (int g = 0; g < groups; ++g) mx = std::max(mx, sk_count(t, g));
+            return mx;
+        };
+        k.G = std::min(target, k.U);
+        while (k.G > 1 && max_pieces(k.G) > BG_MAXP) k.G -= (k.G > 64 ? 16 : 1);
+    }
+    return k;
+}
 
 template <int EPI>
 int launch_bgemm(const BGemmArgs& a, int MT, hipStream_t st) {
-    const int grid = ((a.NT + 3) / 4) * a.S;
-    const size_t lds = (size_t)2 * BG_KC * MT * 64 * sizeof(uint4);
-    static bool big_lds = false;      // 96 / 128 KiB of dynamic LDS need the opt-in (once per instantiation)
-    if (MT >= 3 && !big_lds) {
-        (void)hipFuncSetAttribute((const void*)k_bgemm<3, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
-        (void)hipFuncSetAttribute((const void*)k_bgemm<4, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
-        big_lds = true;
-    }
     switch (MT) {
-        case 1: hipLaunchKernelGGL((k_bgemm<1, EPI>), dim3((unsigned)grid), dim3(256), lds, st, a); break;
-        case 2: hipLaunchKernelGGL((k_bgemm<2, EPI>), dim3((unsigned)grid), dim3(256), lds, st, a); break;
-        case 3: hipLaunchKernelGGL((k_bgemm<3, EPI>), dim3((unsigned)grid), dim3(256), lds, st, a); break;
-        default: hipLaunchKernelGGL((k_bgemm<4, EPI>), dim3((unsigned)grid), dim3(256), lds, st, a); break;
+        case 1: hipLaunchKernelGGL((k_bgemm<1, EPI>), dim3((unsigned)a.sk.G), dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((k_bgemm<2, EPI>), dim3((unsigned)a.sk.G), dim3(256), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((k_bgemm<3, EPI>), dim3((unsigned)a.sk.G), dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((k_bgemm<4, EPI>), dim3((unsigned)a.sk.G), dim3(256), 0, st, a); break;
     }
     return launch_status("k_bgemm");
-}
-
-// split-K factor: fill the 256 CUs, keep at least two activation chunks (32 k-blocks) per slice
-int cham_split(int NT, int KB) {
-    const int groups = (NT + 3) / 4;
-    int S = 1;
-    while (S < CHAM_MAX_SLABS && groups * S < 256 && KB / (S * 2) >= 2 * BG_KC) S *= 2;
-    if (S < CHAM_MAX_SLABS && groups * S < 200 && KB / (S + 1) >= 2 * BG_KC) S += 1;   // e.g. 96 groups: 3 slices
-    return S;
 }
 
 struct ChamPlan {
@@ -101,18 +122,20 @@ struct ChamPlan {
     int M;
     hipStream_t st;
     int MT, KBD, KBF, nch;
-    long long act8;     // floats per fp32 slab of a D-wide output
-    int S_qkv, S_o, S_2;
+    long long act8;     // floats per fp32 piece of a D-wide output
+    SkInfo sk_qkv, sk_o, sk_13, sk_2, sk_head;
     ChamPlan(wmar_cham* g_, int M_, hipStream_t st_) : g(g_), M(M_), st(st_) {
-        MT = g->MT; KBD = g->D / 16; KBF = g->F / 16; nch = (KBD + 15) / 16;
+        MT = g->MT; KBD = g->D / 16; KBF = g->F / 16; nch = (KBD + CHAM_STAT_KB - 1) / CHAM_STAT_KB;
         act8 = (long long)g->D * MT * 32;
-        S_qkv = cham_split((g->D + 2 * g->Dkv) / 32, KBD);
-        S_o = cham_split(g->D / 32, KBD);
-        S_2 = cham_split(g->D / 32, KBF);
+        sk_qkv = sk_for((g->D + 2 * g->Dkv) / 32, KBD, false);
+        sk_o = sk_for(g->D / 32, KBD, false);
+        sk_13 = sk_for(g->F / 16, KBD, false);
+        sk_2 = sk_for(g->D / 32, KBF, false);
+        sk_head = sk_for(g->V / 32, KBD, true);
     }
     BGemmArgs base() const {
         BGemmArgs a{};
-        a.M = M; a.ssq = g->ssq; a.n_chunks = nch; a.K = g->D; a.eps = g->cfg.norm_eps; a.S = 1;
+        a.M = M; a.ssq = g->ssq; a.n_chunks = nch; a.K = g->D; a.eps = g->cfg.norm_eps;
         return a;
     }
     int embed() {
@@ -121,9 +144,9 @@ struct ChamPlan {
         hipLaunchKernelGGL((k_cham_resid<true>), dim3((unsigned)(nch * MT)), dim3(256), 0, st, r);
         return launch_status("k_cham_resid<embed>");
     }
-    int resid(int S) {
+    int resid(const SkInfo& sk) {
         ChamResidArgs r{};
-        r.x = g->x; r.slabs = g->slabs; r.slab_stride = act8; r.S = S; r.ssq = g->ssq; r.KB = KBD; r.MT = MT; r.M = M; r.K = g->D;
+        r.x = g->x; r.slabs = g->slabs; r.slab_stride = act8; r.sk = sk; r.ssq = g->ssq; r.KB = KBD; r.MT = MT; r.M = M; r.K = g->D;
         hipLaunchKernelGGL((k_cham_resid<false>), dim3((unsigned)(nch * MT)), dim3(256), 0, st, r);
         return launch_status("k_cham_resid");
     }
@@ -132,35 +155,41 @@ struct ChamPlan {
         int rc;
         const int Nqkv = g->D + 2 * g->Dkv;
         BGemmArgs q = base();
-        q.Wp = w.wqkv; q.Xp = g->x; q.KB = KBD; q.NT = Nqkv / 32; q.S = S_qkv; q.slabs = g->qkv_slabs;
+        q.Wp = w.wqkv; q.Xp = g->x; q.KB = KBD; q.NT = Nqkv / 32; q.sk = sk_qkv; q.slabs = g->big_slabs;
         q.slab_stride = (long long)Nqkv * MT * 32;
         if ((rc = launch_bgemm<BEPI_SLAB>(q, MT, st))) return rc;
         ChamAttnArgs t{};
         const long long lstride = (long long)g->Mmax * g->Hkv * g->T * g->hd;
-        t.qkv_slabs = g->qkv_slabs; t.slab_stride = q.slab_stride; t.S = S_qkv; t.ssq = g->ssq; t.n_chunks = nch; t.K = g->D;
+        t.qkv_slabs = g->big_slabs; t.slab_stride = q.slab_stride; t.sk = sk_qkv; t.ssq = g->ssq; t.n_chunks = nch; t.K = g->D;
         t.eps = g->cfg.norm_eps; t.qn_w = w.qnw; t.qn_b = w.qnb; t.kn_w = w.knw; t.kn_b = w.knb;
         t.kcache = g->kcache + l * lstride; t.vcache = g->vcache + l * lstride; t.y = g->y; t.pos = g->pos;
         t.D = g->D; t.H = g->H; t.Hkv = g->Hkv; t.Tmax = g->T; t.MT = MT; t.scale = 1.0f / sqrtf((float)g->hd);
-        t.theta = g->cfg.rope_theta;
+        t.rope = g->rope;
         const dim3 grid((unsigned)(M * g->H));
         if (g->hd == 128) hipLaunchKernelGGL((k_cham_attn<128, 2>), grid, dim3(128), 0, st, t);
         else hipLaunchKernelGGL((k_cham_attn<64, 2>), grid, dim3(128), 0, st, t);
         if ((rc = launch_status("k_cham_attn"))) return rc;
         BGemmArgs o = base();
-        o.Wp = w.wo; o.Xp = g->y; o.KB = KBD; o.NT = g->D / 32; o.S = S_o; o.slabs = g->slabs; o.slab_stride = act8;
+        o.Wp = w.wo; o.Xp = g->y; o.KB = KBD; o.NT = g->D / 32; o.sk = sk_o; o.slabs = g->slabs; o.slab_stride = act8;
         if ((rc = launch_bgemm<BEPI_SLAB>(o, MT, st))) return rc;
-        if ((rc = resid(S_o))) return rc;
+        if ((rc = resid(sk_o))) return rc;
         BGemmArgs f = base();
-        f.Wp = w.w13; f.Xp = g->x; f.KB = KBD; f.NT = g->F / 16; f.out_packed = g->hbuf;
-        if ((rc = launch_bgemm<BEPI_SWIGLU>(f, MT, st))) return rc;
+        f.Wp = w.w13; f.Xp = g->x; f.KB = KBD; f.NT = g->F / 16; f.sk = sk_13; f.slabs = g->big_slabs;
+        f.slab_stride = (long long)2 * g->F * MT * 32;
+        if ((rc = launch_bgemm<BEPI_SLAB>(f, MT, st))) return rc;
+        SwigluArgs sw{};
+        sw.slabs = g->big_slabs; sw.slab_stride = f.slab_stride; sw.sk = sk_13; sw.out = g->hbuf; sw.ssq = g->ssq; sw.n_chunks = nch;
+        sw.K = g->D; sw.eps = g->cfg.norm_eps; sw.NT = g->F / 16; sw.MT = MT;
+        hipLaunchKernelGGL(k_cham_swiglu, dim3((unsigned)((sw.NT + 3) / 4), (unsigned)MT), dim3(256), 0, st, sw);
+        if ((rc = launch_status("k_cham_swiglu"))) return rc;
         BGemmArgs d = base();
-        d.Wp = w.w2; d.Xp = g->hbuf; d.KB = KBF; d.NT = g->D / 32; d.S = S_2; d.slabs = g->slabs; d.slab_stride = act8;
+        d.Wp = w.w2; d.Xp = g->hbuf; d.KB = KBF; d.NT = g->D / 32; d.sk = sk_2; d.slabs = g->slabs; d.slab_stride = act8;
         if ((rc = launch_bgemm<BEPI_SLAB>(d, MT, st))) return rc;
-        return resid(S_2);
+        return resid(sk_2);
     }
     int head(float* logits_out) {
         BGemmArgs a = base();
-        a.Wp = g->whead; a.Xp = g->x; a.KB = KBD; a.NT = g->V / 32; a.logits = logits_out; a.V = g->V;
+        a.Wp = g->whead; a.Xp = g->x; a.KB = KBD; a.NT = g->V / 32; a.sk = sk_head; a.logits = logits_out; a.V = g->V;
         return launch_bgemm<BEPI_LOGITS>(a, MT, st);
     }
     int step(bool with_head, float* logits_out) {
@@ -256,9 +285,9 @@ int wmar_cham_create(const wmar_cham_config* cfg, const char* const* names, cons
     TRY(g->mem.alloc(&g->x, Mpad * D / 8));
     TRY(g->mem.alloc(&g->y, Mpad * D / 8));
     TRY(g->mem.alloc(&g->hbuf, Mpad * F / 8));
-    TRY(g->mem.alloc(&g->slabs, (size_t)CHAM_MAX_SLABS * Mpad * D));
-    TRY(g->mem.alloc(&g->qkv_slabs, (size_t)CHAM_MAX_SLABS * Mpad * Nqkv));
-    TRY(g->mem.alloc(&g->ssq, (size_t)((D / 16 + 15) / 16) * Mpad));
+    TRY(g->mem.alloc(&g->slabs, (size_t)BG_MAXP * Mpad * D));
+    TRY(g->mem.alloc(&g->big_slabs, (size_t)BG_MAXP * Mpad * (size_t)std::max(Nqkv, 2 * F)));
+    TRY(g->mem.alloc(&g->ssq, (size_t)((D / 16 + CHAM_STAT_KB - 1) / CHAM_STAT_KB) * Mpad));
     const size_t kv = (size_t)L * g->Mmax * Hkv * g->T * hd;
     TRY(g->mem.alloc(&g->kcache, kv));
     TRY(g->mem.alloc(&g->vcache, kv));
@@ -268,6 +297,12 @@ int wmar_cham_create(const wmar_cham_config* cfg, const char* const* names, cons
     TRY(g->mem.alloc(&g->pos, Mpad));
     TRY(g->mem.alloc(&g->ids, (size_t)g->Mmax * (size_t)(g->T + 1)));
     TRY(g->mem.alloc(&g->ctr, 4));
+    TRY(g->mem.alloc(&g->rope, (size_t)g->T * (hd / 2)));
+    if (rc == WMAR_OK) {
+        const long long n = (long long)g->T * (hd / 2);
+        hipLaunchKernelGGL(k_rope_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g->rope, g->T, hd / 2, cfg->rope_theta);
+        rc = launch_status("k_rope_table");
+    }
     if (rc == WMAR_OK) {
         hipError_t er = hipMemsetAsync(g->x, 0, Mpad * D * 2, st);
         if (er == hipSuccess) er = hipMemsetAsync(g->y, 0, Mpad * D * 2, st);
@@ -305,8 +340,8 @@ int wmar_cham_forward_tokens(wmar_cham* g, const int64_t* tok_dev, const int32_t
 
 int wmar_cham_generate_image(wmar_cham* g, const wmar_wm_ctx* wm, const int64_t* prompt_tokens_host,
                              const int32_t* prompt_lens_host, int64_t B, const wmar_cham_sample_params* sp,
-                             const uint32_t* allow_dev, const float* q_dev, int32_t n_tokens, int64_t* tokens_out_dev,
-                             void* stream) {
+                             const uint32_t* allow_dev, const int32_t* allow_ids_dev, int32_t n_allow, const float* q_dev,
+                             int32_t n_tokens, int64_t* tokens_out_dev, void* stream) {
     WMAR_REQUIRE(g && prompt_tokens_host && prompt_lens_host && sp && q_dev && tokens_out_dev, "cham_generate_image: null argument");
     WMAR_REQUIRE(B >= 1 && 3 * B <= g->Mmax, "cham_generate_image: batch %lld needs %lld rows, engine has %d", (long long)B,
                  (long long)(3 * B), g->Mmax);
@@ -369,6 +404,7 @@ int wmar_cham_generate_image(wmar_cham* g, const wmar_wm_ctx* wm, const int64_t*
     a.past_append = g->ids; a.trace = nullptr; a.B = B;
     a.logits_img = g->logits + (long long)B * V; a.logits_uncond = g->logits + 2ll * B * V;
     a.g_text = sp->guidance_scale_text; a.g_image = sp->guidance_scale_image; a.allow = allow_dev;
+    if (allow_ids_dev && n_allow > 0) { a.gather = allow_ids_dev; a.Vsrc = V; a.V = n_allow; }
 
     auto sample = [&](hipStream_t s) -> int {
         int r = launch_sample_fused(a, s);

@@ -134,151 +134,248 @@ __device__ __forceinline__ float cham_rstd(const double* __restrict__ ssq, int n
 }
 
 // ------------------------------------------------------------------------------- GEMM
-constexpr int BG_KC = 16;        // k-blocks (of 16) per staged activation chunk: 256 columns
-enum { BEPI_SLAB = 0, BEPI_SWIGLU = 1, BEPI_LOGITS = 2 };
+// Work decomposition ("stream-K"): a unit is (group of 8 column tiles, chunk of BG_KC k-blocks).
+// The grid is a fixed number of workgroups G (one or two per CU); workgroup w takes the
+// contiguous units [w*U/G, (w+1)*U/G) in (group-major, chunk-minor) order, so every CU streams the
+// same number of weight bytes whatever N and K are.  When a workgroup leaves a group it writes its
+// partial sums as one "piece" of that group; consumers add the pieces of a group in piece order
+// (fixed, so results do not depend on timing).  sk_* below is the shared index arithmetic.
+constexpr int BG_KC = 8;         // k-blocks (of 16) per unit: 128 columns
+constexpr int BG_TG = 8;         // column tiles per group: 4 waves x 2 tiles share one staged activation chunk
+constexpr int BG_MAXP = 16;      // pieces per group the slab buffers are sized for
+enum { BEPI_SLAB = 0, BEPI_LOGITS = 2 };
+
+struct SkInfo { int C, U, G; };  // chunks per group, total units, workgroups
+__host__ __device__ __forceinline__ int sk_wg_of(const SkInfo& k, long long u) { return (int)(((u + 1) * k.G - 1) / k.U); }
+__host__ __device__ __forceinline__ int sk_first(const SkInfo& k, int g) { return sk_wg_of(k, (long long)g * k.C); }
+__host__ __device__ __forceinline__ int sk_count(const SkInfo& k, int g) {
+    return sk_wg_of(k, (long long)g * k.C + k.C - 1) - sk_first(k, g) + 1;
+}
 
 struct BGemmArgs {
     const uint4* Wp;       // [NT][KB][64]
     const uint4* Xp;       // [KB][MT][64]
-    int KB, NT, S, M;
-    float* slabs;          // BEPI_SLAB: [S][NT*2][MT][64][8] fp32 partial sums
-    long long slab_stride; // floats
-    uint4* out_packed;     // BEPI_SWIGLU: [NT][MT][64] bf16x8
-    float* logits;         // BEPI_LOGITS: [M][V]
+    int KB, NT, M;
+    SkInfo sk;
+    float* slabs;          // BEPI_SLAB: [piece][NT*2][MT][64][8] fp32 partial sums
+    long long slab_stride; // floats per piece
+    float* logits;         // BEPI_LOGITS: [M][V]  (every workgroup must own whole groups)
     int V;
-    const double* ssq; int n_chunks; int K; float eps;   // 1/rms of the input rows (SWIGLU, LOGITS)
+    const double* ssq; int n_chunks; int K; float eps;   // 1/rms of the input rows (LOGITS)
 };
 
 template <int MT, int EPI>
 __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint4 xs[];   // [2][BG_KC][MT][64]
+    __shared__ __attribute__((aligned(16))) uint4 xs[2 * BG_KC * MT * 64];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int NG = (a.NT + 3) / 4;
-    const int ng = blockIdx.x % NG, s = blockIdx.x / NG;
-    const int nt = ng * 4 + w;
-    const bool live = nt < a.NT;
-    const int ntc = live ? nt : a.NT - 1;
-    const int kb0 = (int)((long long)s * a.KB / a.S), kb1 = (int)((long long)(s + 1) * a.KB / a.S);
-    const int nchunk = (kb1 - kb0 + BG_KC - 1) / BG_KC;
-    const uint4* Wp = a.Wp + (long long)ntc * a.KB * 64 + lane;
+    const SkInfo sk = a.sk;
+    const long long u0 = (long long)blockIdx.x * sk.U / sk.G, u1 = ((long long)blockIdx.x + 1) * sk.U / sk.G;
+    const int nu = (int)(u1 - u0);
     constexpr int XPT = BG_KC * MT / 4;       // uint4 per thread per chunk (256 threads)
 
-    f32x16 acc[MT];
+    f32x16 acc[2][MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.f;
 
     float rstd[MT];
-    if (EPI != BEPI_SLAB) {
+    if (EPI == BEPI_LOGITS) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) rstd[i] = cham_rstd(a.ssq, a.n_chunks, MT * 32, i * 32 + (lane & 31), a.K, a.eps);
     }
-
-    uint4 wA[BG_KC], wB[BG_KC], xr[XPT];
-    // k-blocks past the slice end are clamped: they reload the last block and are skipped by the MFMA loop
-#define CH_LOADW(WB, C)                                                                   \
-    _Pragma("unroll") for (int u = 0; u < BG_KC; ++u) {                                   \
-        const int kk = min(kb0 + (C) * BG_KC + u, kb1 - 1);                               \
-        WB[u] = ld_nt_u4(Wp + (long long)kk * 64);                      \
+    // rows past M are padding: their lanes are not fetched (they read as zeros)
+    bool xact[XPT];
+#pragma unroll
+    for (int u = 0; u < XPT; ++u) {
+        const int e = (threadIdx.x + u * 256) % (MT * 64);
+        xact[u] = (e / 64) * 32 + (e & 31) < a.M;
     }
-#define CH_LOADX(C)                                                                       \
-    _Pragma("unroll") for (int u = 0; u < XPT; ++u) {                                     \
-        const int e = threadIdx.x + u * 256;              /* element of [BG_KC][MT][64] */ \
-        const int kk = min(kb0 + (C) * BG_KC + e / (MT * 64), kb1 - 1);                   \
-        xr[u] = a.Xp[(long long)kk * (MT * 64) + e % (MT * 64)];                          \
+
+    uint4 wA[2][BG_KC], wB[2][BG_KC], xr[XPT];
+    // unit ui of this workgroup: group g, k-blocks [c*BG_KC, ...) clamped to KB-1 (clamped blocks are skipped by the MFMA loop)
+#define CH_LOADW(WB, UI)                                                                  \
+    {                                                                                     \
+        const long long uu = u0 + (UI);                                                   \
+        const int g_ = (int)(uu / sk.C), c_ = (int)(uu % sk.C);                           \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                   \
+            const int nt_ = min(g_ * BG_TG + 2 * w + t, a.NT - 1);                        \
+            const uint4* wp_ = a.Wp + (long long)nt_ * a.KB * 64 + lane;                  \
+            _Pragma("unroll") for (int u = 0; u < BG_KC; ++u)                             \
+                WB[t][u] = ld_nt_u4(wp_ + (long long)min(c_ * BG_KC + u, a.KB - 1) * 64); \
+        }                                                                                 \
+    }
+#define CH_LOADX(UI)                                                                      \
+    {                                                                                     \
+        const int c_ = (int)((u0 + (UI)) % sk.C);                                         \
+        _Pragma("unroll") for (int u = 0; u < XPT; ++u) {                                 \
+            const int e = threadIdx.x + u * 256;              /* element of [BG_KC][MT][64] */ \
+            const int kk = min(c_ * BG_KC + e / (MT * 64), a.KB - 1);                     \
+            xr[u] = make_uint4(0u, 0u, 0u, 0u);                                           \
+            if (xact[u]) xr[u] = a.Xp[(long long)kk * (MT * 64) + e % (MT * 64)];         \
+        }                                                                                 \
     }
 #define CH_STOREX(BUF)                                                                    \
     _Pragma("unroll") for (int u = 0; u < XPT; ++u) xs[(BUF) * (BG_KC * MT * 64) + threadIdx.x + u * 256] = xr[u];
 #define CH_MMA1(WB, BUF, U)                                                               \
     {                                                                                     \
-        const bf16x8 wv = __builtin_bit_cast(bf16x8, WB[U]);                              \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                  \
-            const uint4 xv = xs[(BUF) * (BG_KC * MT * 64) + ((U) * MT + i) * 64 + lane];  \
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, __builtin_bit_cast(bf16x8, xv), acc[i], 0, 0, 0); \
+        uint4 xv[MT];                                                                     \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) xv[i] = xs[(BUF) * (BG_KC * MT * 64) + ((U) * MT + i) * 64 + lane]; \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                   \
+            const bf16x8 wv = __builtin_bit_cast(bf16x8, WB[t][U]);                       \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i)                                \
+                acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, __builtin_bit_cast(bf16x8, xv[i]), acc[t][i], 0, 0, 0); \
         }                                                                                 \
     }
-#define CH_MMA(WB, BUF, C)                                                                \
+    // MFMAs of unit UI, then (when the workgroup leaves the group) the epilogue of that group
+#define CH_UNIT(WB, BUF, UI)                                                              \
     {                                                                                     \
-        const int nk = kb1 - (kb0 + (C) * BG_KC);                                         \
+        const long long uu = u0 + (UI);                                                   \
+        const int g_ = (int)(uu / sk.C), c_ = (int)(uu % sk.C);                           \
+        const int nk = a.KB - c_ * BG_KC;                                                 \
         if (nk >= BG_KC) {                                                                \
             _Pragma("unroll") for (int u = 0; u < BG_KC; ++u) CH_MMA1(WB, BUF, u)         \
         } else {                                                                          \
             _Pragma("unroll") for (int u = 0; u < BG_KC; ++u)                             \
                 if (u < nk) CH_MMA1(WB, BUF, u)                                           \
         }                                                                                 \
+        if ((UI) + 1 == nu || c_ + 1 == sk.C) flush(g_);                                  \
     }
-    CH_LOADW(wA, 0)
+    auto flush = [&](int g) {
+        const int hh = lane >> 5;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int nt = g * BG_TG + 2 * w + t;
+            if (nt < a.NT) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    if (EPI == BEPI_SLAB) {
+                        const int piece = (int)blockIdx.x - sk_first(sk, g);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            float* dst = a.slabs + (long long)piece * a.slab_stride + ((((long long)nt * 2 + b) * MT + i) * 64 + lane) * 8;
+                            *(float4*)dst = make_float4(acc[t][i][8 * b], acc[t][i][8 * b + 1], acc[t][i][8 * b + 2], acc[t][i][8 * b + 3]);
+                            *(float4*)(dst + 4) = make_float4(acc[t][i][8 * b + 4], acc[t][i][8 * b + 5], acc[t][i][8 * b + 6], acc[t][i][8 * b + 7]);
+                        }
+                    } else {
+                        const int m = i * 32 + (lane & 31);
+                        if (m < a.M) {
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) {
+                                float* dst = a.logits + (long long)m * a.V + nt * 32 + 16 * b + 8 * hh;
+                                float o[8];
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) o[j] = bf_round(rstd[i] * acc[t][i][8 * b + j]);   // logits.float() of a bf16 Linear
+                                *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+                                *(float4*)(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.f;
+        }
+    };
+    if (nu == 0) return;
     CH_LOADX(0)
+    CH_LOADW(wA, 0)
     __builtin_amdgcn_sched_barrier(0);
     CH_STOREX(0)
     __syncthreads();
-    for (int c = 0; c < nchunk; c += 2) {
-        if (c + 1 < nchunk) { CH_LOADW(wB, c + 1) CH_LOADX(c + 1) }
+    for (int ui = 0; ui < nu; ui += 2) {
+        if (ui + 1 < nu) { CH_LOADX(ui + 1) CH_LOADW(wB, ui + 1) }   // X first: waiting for it must not drain the weight loads
         __builtin_amdgcn_sched_barrier(0);
-        CH_MMA(wA, 0, c)
+        CH_UNIT(wA, 0, ui)
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < nchunk) { CH_STOREX(1) }
+        if (ui + 1 < nu) { CH_STOREX(1) }
         __syncthreads();
-        if (c + 1 >= nchunk) break;
-        if (c + 2 < nchunk) { CH_LOADW(wA, c + 2) CH_LOADX(c + 2) }
+        if (ui + 1 >= nu) break;
+        if (ui + 2 < nu) { CH_LOADX(ui + 2) CH_LOADW(wA, ui + 2) }
         __builtin_amdgcn_sched_barrier(0);
-        CH_MMA(wB, 1, c + 1)
+        CH_UNIT(wB, 1, ui + 1)
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 2 < nchunk) { CH_STOREX(0) }
+        if (ui + 2 < nu) { CH_STOREX(0) }
         __syncthreads();
     }
 #undef CH_LOADW
 #undef CH_LOADX
 #undef CH_STOREX
-#undef CH_MMA
 #undef CH_MMA1
-    if (!live) return;
-    const int h = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        if (EPI == BEPI_SLAB) {
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                float* dst = a.slabs + (long long)s * a.slab_stride + ((((long long)nt * 2 + b) * MT + i) * 64 + lane) * 8;
-                *(float4*)dst = make_float4(acc[i][8 * b], acc[i][8 * b + 1], acc[i][8 * b + 2], acc[i][8 * b + 3]);
-                *(float4*)(dst + 4) = make_float4(acc[i][8 * b + 4], acc[i][8 * b + 5], acc[i][8 * b + 6], acc[i][8 * b + 7]);
-            }
-        } else if (EPI == BEPI_SWIGLU) {
-            // x13 = bf16(w13 x); silu and the product are bf16 ops (FeedForward.forward, transformer.py:214-216)
-            float o[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x1 = bf_round(rstd[i] * acc[i][j]);
-                const float x3 = bf_round(rstd[i] * acc[i][8 + j]);
-                const float sl = bf_round(x1 / (1.0f + expf(-x1)));
-                o[j] = sl * x3;
-            }
-            a.out_packed[((long long)nt * MT + i) * 64 + lane] = bf_pack8(o);
-        } else {
-            const int m = i * 32 + (lane & 31);
-            if (m < a.M) {
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    float* dst = a.logits + (long long)m * a.V + nt * 32 + 16 * b + 8 * h;
-                    float o[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = bf_round(rstd[i] * acc[i][8 * b + j]);   // logits.float() of a bf16 Linear
-                    *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
-                    *(float4*)(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
-                }
-            }
-        }
+#undef CH_UNIT
+}
+
+// h = silu(x1) * x3 from the pieces of the w13 GEMM (FeedForward.forward, transformer.py:214-216):
+// x13 = bf16(rstd * sum of pieces); silu and the product are bf16 ops.  Tile nt of that GEMM holds
+// x1 features 16nt..16nt+15 (block 2nt) and the matching x3 features (block 2nt+1); the result is
+// k-block nt of w2's input.  One wave per (tile, row tile).
+struct SwigluArgs {
+    const float* slabs; long long slab_stride; SkInfo sk;
+    uint4* out;            // [NT][MT][64]
+    const double* ssq; int n_chunks; int K; float eps;
+    int NT, MT;
+};
+static __global__ __launch_bounds__(256) void k_cham_swiglu(SwigluArgs a) {
+    // grid: (ceil(NT / 4), MT); the four waves take four consecutive tiles of one row tile
+    __shared__ double red[8][32];
+    const int mt = blockIdx.y, lane = threadIdx.x & 63;
+    const int nt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    {   // 1/rms of the 32 rows: 8 thread groups x (n_chunks / 8) statistics chunks each
+        const int r = threadIdx.x & 31, grp = threadIdx.x >> 5;
+        double ssum = 0;
+        for (int c = grp; c < a.n_chunks; c += 8) ssum += a.ssq[(long long)c * a.MT * 32 + mt * 32 + r];
+        red[grp][r] = ssum;
     }
+    __syncthreads();
+    if (nt >= a.NT) return;
+    double tot = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tot += red[i][lane & 31];
+    const float rstd = rsqrtf((float)(tot / (double)a.K) + a.eps);
+    const int g = nt / BG_TG, np = sk_count(a.sk, g);
+    float x1[8], x3[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { x1[j] = 0.f; x3[j] = 0.f; }
+    const long long i1 = ((((long long)nt * 2) * a.MT + mt) * 64 + lane) * 8, i3 = ((((long long)nt * 2 + 1) * a.MT + mt) * 64 + lane) * 8;
+    for (int s0 = 0; s0 < np; s0 += 4) {        // four pieces per round trip
+        float4 a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const long long po = (long long)min(s0 + d, np - 1) * a.slab_stride;
+            a0[d] = *(const float4*)(a.slabs + po + i1); a1[d] = *(const float4*)(a.slabs + po + i1 + 4);
+            b0[d] = *(const float4*)(a.slabs + po + i3); b1[d] = *(const float4*)(a.slabs + po + i3 + 4);
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            if (s0 + d < np) {
+                x1[0] += a0[d].x; x1[1] += a0[d].y; x1[2] += a0[d].z; x1[3] += a0[d].w;
+                x1[4] += a1[d].x; x1[5] += a1[d].y; x1[6] += a1[d].z; x1[7] += a1[d].w;
+                x3[0] += b0[d].x; x3[1] += b0[d].y; x3[2] += b0[d].z; x3[3] += b0[d].w;
+                x3[4] += b1[d].x; x3[5] += b1[d].y; x3[6] += b1[d].z; x3[7] += b1[d].w;
+            }
+    }
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float u1 = bf_round(rstd * x1[j]), u3 = bf_round(rstd * x3[j]);
+        o[j] = bf_round(u1 / (1.0f + expf(-u1))) * u3;
+    }
+    a.out[((long long)nt * a.MT + mt) * 64 + lane] = bf_pack8(o);
 }
 
 // ------------------------------------------------------------- embedding / residual update
-// x = tok_embeddings[tok[m]] (bf16), per-chunk sums of squares.  One workgroup per (chunk of 16
-// k-blocks, row tile); wave w takes k-blocks w, w+4, ...
+// x = tok_embeddings[tok[m]] (bf16), per-chunk sums of squares.  One workgroup per (chunk of
+// CHAM_STAT_KB k-blocks, row tile), one k-block per wave: the kernel is a few dependent L2 round
+// trips over little data, so it wants many small workgroups.
+constexpr int CHAM_STAT_KB = 4;
 struct ChamResidArgs {
     uint4* x;                   // [KB][MT][64]
-    const float* slabs; long long slab_stride; int S;   // residual branch: sum of S fp32 slabs, rounded to bf16 first
+    const float* slabs; long long slab_stride; SkInfo sk;   // residual branch: sum of the group's pieces, rounded to bf16 first
     const uint16_t* emb;        // embed: [V][K] bf16
     const long long* tok;       // [M]
     double* ssq;                // [n_chunks][Mpad]
@@ -291,7 +388,7 @@ __global__ __launch_bounds__(256) void k_cham_resid(ChamResidArgs a) {
     const int c = blockIdx.x / a.MT, mt = blockIdx.x % a.MT;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int m = mt * 32 + (lane & 31), h = lane >> 5;
-    const int kb0 = c * 16, kb1 = min(a.KB, kb0 + 16);
+    const int kb0 = c * CHAM_STAT_KB, kb1 = min(a.KB, kb0 + CHAM_STAT_KB);
     const long long tk = (EMBED && m < a.M) ? a.tok[m] : 0;
     double ss = 0.0;
     for (int kb = kb0 + w; kb < kb1; kb += 4) {
@@ -308,11 +405,20 @@ __global__ __launch_bounds__(256) void k_cham_resid(ChamResidArgs a) {
             bf_unpack8(a.x[idx], xv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) br[j] = 0.f;
-            for (int sidx = 0; sidx < a.S; ++sidx) {
-                const float* sp = a.slabs + (long long)sidx * a.slab_stride + idx * 8;
-                const float4 p0 = *(const float4*)sp, p1 = *(const float4*)(sp + 4);
-                br[0] += p0.x; br[1] += p0.y; br[2] += p0.z; br[3] += p0.w;
-                br[4] += p1.x; br[5] += p1.y; br[6] += p1.z; br[7] += p1.w;
+            const int np = sk_count(a.sk, (kb >> 1) / BG_TG);
+            for (int s0 = 0; s0 < np; s0 += 8) {        // eight pieces per round trip
+                float4 p0[8], p1[8];
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    const float* sp = a.slabs + (long long)min(s0 + d, np - 1) * a.slab_stride + idx * 8;
+                    p0[d] = *(const float4*)sp; p1[d] = *(const float4*)(sp + 4);
+                }
+#pragma unroll
+                for (int d = 0; d < 8; ++d)
+                    if (s0 + d < np) {
+                        br[0] += p0[d].x; br[1] += p0[d].y; br[2] += p0[d].z; br[3] += p0[d].w;
+                        br[4] += p1[d].x; br[5] += p1[d].y; br[6] += p1[d].z; br[7] += p1[d].w;
+                    }
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) r[j] = bf_round(xv[j] + bf_round(br[j]));   // h = x + Linear(...) in bf16
@@ -330,21 +436,33 @@ __global__ __launch_bounds__(256) void k_cham_resid(ChamResidArgs a) {
 
 // ------------------------------------------------------------------------ decode attention
 struct ChamAttnArgs {
-    const float* qkv_slabs; long long slab_stride; int S;   // [S][(D + 2*Dkv)/16][MT][64][8]
+    const float* qkv_slabs; long long slab_stride; SkInfo sk;   // pieces of [(D + 2*Dkv)/16][MT][64][8]
     const double* ssq; int n_chunks; int K; float eps;      // attention_norm statistics of the input rows
     const float *qn_w, *qn_b, *kn_w, *kn_b;                 // [hd] LayerNorm(head_dim) of q and k; null: no qk normalisation
     uint16_t* kcache; uint16_t* vcache;                     // [M][Hkv][Tmax][hd] bf16 (this layer)
     uint4* y;                                               // packed [D/16][MT][64]
     const int* pos;                                         // [M] position of each row's token
     int D, H, Hkv, Tmax, MT;
-    float scale, theta;
+    float scale;
+    const float2* rope;                                     // [Tmax][hd/2] (cos, sin) of position * theta^(-2i/hd)
 };
+
+// (cos, sin)(p * theta^(-2i/hd)) in fp32 -- what rope_padded evaluates per element, tabulated once per engine
+static __global__ void k_rope_table(float2* tab, int T, int half, float theta) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)T * half) return;
+    const int p = (int)(idx / half), i = (int)(idx % half);
+    const float freq = powf(theta, -2.0f * (float)i / (float)(2 * half));
+    float sn, cs;
+    sincosf((float)p * freq, &sn, &cs);
+    tab[idx] = make_float2(cs, sn);
+}
 
 template <int HD, int NWA>
 __global__ __launch_bounds__(NWA * 64) void k_cham_attn(ChamAttnArgs a) {
     constexpr int LPR = HD / 8;            // lanes per cached row (8 bf16 each)
     constexpr int RPI = 64 / LPR;          // rows per wave-wide load
-    constexpr int CH = 8;
+    constexpr int CH = 4;
     constexpr int ROWS = CH * RPI;
     __shared__ __attribute__((aligned(16))) float part[NWA][HD + 4];
     __shared__ __attribute__((aligned(16))) float qkv_s[3][HD];
@@ -373,7 +491,10 @@ __global__ __launch_bounds__(NWA * 64) void k_cham_attn(ChamAttnArgs a) {
         double ssum = 0;
         for (int c = lane; c < a.n_chunks; c += 64) ssum += a.ssq[(long long)c * a.MT * 32 + m];
         float v3[3][8];
+        float4 rp0 = make_float4(1.f, 0.f, 1.f, 0.f), rp1 = rp0;
         if (rsel == 0) {
+            const float4* rp = (const float4*)(a.rope + (long long)P * (HD / 2) + sub * 4);
+            rp0 = rp[0]; rp1 = rp[1];
             const int mt = m >> 5;
 #pragma unroll
             for (int which = 0; which < 3; ++which) {
@@ -381,11 +502,20 @@ __global__ __launch_bounds__(NWA * 64) void k_cham_attn(ChamAttnArgs a) {
                 const long long idx = ((((long long)(n >> 4)) * a.MT + mt) * 64 + (m & 31) + 32 * ((n >> 3) & 1)) * 8;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v3[which][j] = 0.f;
-                for (int sidx = 0; sidx < a.S; ++sidx) {
-                    const float* sp = a.qkv_slabs + (long long)sidx * a.slab_stride + idx;
-                    const float4 p0 = *(const float4*)sp, p1 = *(const float4*)(sp + 4);
-                    v3[which][0] += p0.x; v3[which][1] += p0.y; v3[which][2] += p0.z; v3[which][3] += p0.w;
-                    v3[which][4] += p1.x; v3[which][5] += p1.y; v3[which][6] += p1.z; v3[which][7] += p1.w;
+                const int np = sk_count(a.sk, (n >> 5) / BG_TG);
+                for (int s0 = 0; s0 < np; s0 += 4) {      // four pieces per round trip
+                    float4 p0[4], p1[4];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const float* sp = a.qkv_slabs + (long long)min(s0 + d, np - 1) * a.slab_stride + idx;
+                        p0[d] = *(const float4*)sp; p1[d] = *(const float4*)(sp + 4);
+                    }
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        if (s0 + d < np) {
+                            v3[which][0] += p0[d].x; v3[which][1] += p0[d].y; v3[which][2] += p0[d].z; v3[which][3] += p0[d].w;
+                            v3[which][4] += p1[d].x; v3[which][5] += p1[d].y; v3[which][6] += p1[d].z; v3[which][7] += p1[d].w;
+                        }
                 }
             }
         }
@@ -424,10 +554,8 @@ __global__ __launch_bounds__(NWA * 64) void k_cham_attn(ChamAttnArgs a) {
             for (int which = 0; which < 2; ++which)
 #pragma unroll
                 for (int p2 = 0; p2 < 4; ++p2) {
-                    const int i = sub * 4 + p2;
-                    const float freq = powf(a.theta, -2.0f * (float)i / (float)HD);
-                    float sn, cs;
-                    sincosf((float)P * freq, &sn, &cs);
+                    const float cs = p2 == 0 ? rp0.x : (p2 == 1 ? rp0.z : (p2 == 2 ? rp1.x : rp1.z));
+                    const float sn = p2 == 0 ? rp0.y : (p2 == 1 ? rp0.w : (p2 == 2 ? rp1.y : rp1.w));
                     const float x0 = v3[which][2 * p2], x1 = v3[which][2 * p2 + 1];
                     v3[which][2 * p2] = bf_round(x0 * cs - x1 * sn);
                     v3[which][2 * p2 + 1] = bf_round(x0 * sn + x1 * cs);

@@ -58,6 +58,11 @@ struct SampArgs {
     float g_text, g_image;
     // AllowOnlyTokensLogitsProcessor (logits_processor.py:135-156): bit v clear -> logit v = -inf (after the watermark bias)
     const uint32_t* allow;       // nullable [V/32]
+    // Row compaction: with `gather` (ascending source ids, int32 [V]) the row worked on is logits[gather[0..V)] -- exact
+    // when every other entry would be -inf anyway (allow-only list); V is then the compact length, Vsrc the logits' width.
+    // The token written is gather[argmax].
+    const int* gather;           // nullable
+    long long Vsrc;
 };
 
 int launch_sample_fused(const SampArgs& a, hipStream_t st);

@@ -132,13 +132,16 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
     const long long step = a.step_dev ? (long long)*a.step_dev : 0;
     const long long* past = a.past ? a.past + b * a.past_stride : nullptr;
     const uint32_t* grow = (past || a.wm.seed_mode == WMAR_SEED_FIXED) ? wm_row(a.wm, past, t) : nullptr;
-    const float* lg = a.logits + b * V;
-    const float* ul = a.logits_uncond ? a.logits_uncond + b * V : nullptr;
-    const float* il = a.logits_img ? a.logits_img + b * V : nullptr;
+    const int* gth = a.gather;
+    const long long Vs = gth ? a.Vsrc : V;          // width of the source rows
+#define WMAR_SRC(v) (gth ? (long long)gth[v] : (long long)(v))
+    const float* lg = a.logits + b * Vs;
+    const float* ul = a.logits_uncond ? a.logits_uncond + b * Vs : nullptr;
+    const float* il = a.logits_img ? a.logits_img + b * Vs : nullptr;
     const float cfg = (ul && !il) ? a.cfg_scale[step] : 0.f;
-    const float* q = a.q + step * a.q_step_stride + b * V;
+    const float* q = a.q + step * a.q_step_stride + b * Vs;
     float* x = a.scratch + b * V;
-    float* trace = a.trace ? a.trace + (step * a.B + b) * V : nullptr;
+    float* trace = a.trace ? a.trace + (step * a.B + b) * Vs : nullptr;
     const float T = a.temperature;
     const float delta = a.wm.delta;
     float xr[EPT > 0 ? EPT : 1];
@@ -160,21 +163,23 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
 #pragma unroll
         for (int i = 0; i < (EPT > 0 ? EPT : 1); ++i) {
             const long long v = tid + (long long)i * SAMP_THREADS;
-            lv[i] = v < V ? lg[v] : 0.f;
+            const long long sv = v < V ? WMAR_SRC(v) : 0;
+            lv[i] = v < V ? lg[sv] : 0.f;
             if (il && v < V) {
-                const float u = ul[v], im = il[v];
+                const float u = ul[sv], im = il[sv];
                 const float d1 = im - u; const float t1 = a.g_image * d1; const float s1 = u + t1;
                 const float d2 = lv[i] - im; const float t2 = a.g_text * d2; lv[i] = s1 + t2;
-            } else if (ul && v < V) { const float u = ul[v]; const float dlt = lv[i] - u; const float sc = dlt * cfg; lv[i] = u + sc; }
+            } else if (ul && v < V) { const float u = ul[sv]; const float dlt = lv[i] - u; const float sc = dlt * cfg; lv[i] = u + sc; }
         }
 #pragma unroll
         for (int i = 0; i < (EPT > 0 ? EPT : 1); ++i) {
             const long long v = tid + (long long)i * SAMP_THREADS;
             if (v < V) {
                 float xv = lv[i];
-                if (trace) trace[v] = xv;
-                if (grow && ((grow[v >> 5] >> (v & 31)) & 1u)) xv = xv + delta;
-                if (a.allow && !((a.allow[v >> 5] >> (v & 31)) & 1u)) xv = -INFINITY;
+                const long long sv = WMAR_SRC(v);
+                if (trace) trace[sv] = xv;
+                if (grow && ((grow[sv >> 5] >> (sv & 31)) & 1u)) xv = xv + delta;
+                if (a.allow && !((a.allow[sv >> 5] >> (sv & 31)) & 1u)) xv = -INFINITY;
                 xv = xv / T;
                 x[v] = xv;
                 xr[i] = xv;
@@ -183,15 +188,16 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
         }
     } else {
         for (long long v = tid; v < V; v += SAMP_THREADS) {
-            float xv = lg[v];
+            const long long sv = WMAR_SRC(v);
+            float xv = lg[sv];
             if (il) {
-                const float u = ul[v], im = il[v];
+                const float u = ul[sv], im = il[sv];
                 const float d1 = im - u; const float t1 = a.g_image * d1; const float s1 = u + t1;
                 const float d2 = xv - im; const float t2 = a.g_text * d2; xv = s1 + t2;
-            } else if (ul) { const float u = ul[v]; const float dlt = xv - u; const float sc = dlt * cfg; xv = u + sc; }
-            if (trace) trace[v] = xv;
-            if (grow && ((grow[v >> 5] >> (v & 31)) & 1u)) xv = xv + delta;
-            if (a.allow && !((a.allow[v >> 5] >> (v & 31)) & 1u)) xv = -INFINITY;
+            } else if (ul) { const float u = ul[sv]; const float dlt = xv - u; const float sc = dlt * cfg; xv = u + sc; }
+            if (trace) trace[sv] = xv;
+            if (grow && ((grow[sv >> 5] >> (sv & 31)) & 1u)) xv = xv + delta;
+            if (a.allow && !((a.allow[sv >> 5] >> (sv & 31)) & 1u)) xv = -INFINITY;
             xv = xv / T;
             x[v] = xv;
             kmax = max(kmax, wmar_f32_key(xv));
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
 #pragma unroll
         for (int i = 0; i < (EPT > 0 ? EPT : 1); ++i) {
             const long long v = tid + (long long)i * SAMP_THREADS;
-            qv[i] = v < V ? q[v] : 1.f;
+            qv[i] = v < V ? q[WMAR_SRC(v)] : 1.f;
         }
     }
     if (EPT > 0) {
@@ -371,7 +377,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
             const uint32_t k = wmar_f32_key(xv);
             const bool kept = k >= thr_key && (k > bkey || (k == bkey && v >= bidx));
             const float e = kept ? wmar_expf(xv - m) : 0.0f;
-            const float r = (e / Sf2) / q[v];
+            const float r = (e / Sf2) / q[WMAR_SRC(v)];
             if (r > best) { best = r; besti = (int)v; }
         }
     }
@@ -386,9 +392,11 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
     if (tid == 0) {
         for (int i = 1; i < SAMP_WAVES; ++i)
             if (red_f[i] > best || (red_f[i] == best && red_i[i] < besti)) { best = red_f[i]; besti = red_i[i]; }
-        a.tok_out[b * a.tok_out_stride + step] = besti;
-        if (a.past_append) a.past_append[b * a.past_stride + t] = besti;
+        const long long tokv = WMAR_SRC(besti);
+        a.tok_out[b * a.tok_out_stride + step] = tokv;
+        if (a.past_append) a.past_append[b * a.past_stride + t] = tokv;
     }
+#undef WMAR_SRC
 }
 
 // ---------------------------------------------------------------------------- detector
@@ -560,8 +568,8 @@ int wmar_sample_fused(const wmar_wm_ctx* wm, const float* logits_dev, int64_t B,
 
 int wmar_cham_sample(const wmar_wm_ctx* wm, const float* logits3_dev, int64_t B, int64_t V, const int64_t* past_ids_dev,
                      int64_t t, int64_t past_stride, float temperature, double top_p, float guidance_scale_text,
-                     float guidance_scale_image, const uint32_t* allow_dev, const float* q_dev, float* scratch_dev,
-                     int64_t* tok_out_dev, void* stream) {
+                     float guidance_scale_image, const uint32_t* allow_dev, const int32_t* allow_ids_dev, int32_t n_allow,
+                     const float* q_dev, float* scratch_dev, int64_t* tok_out_dev, void* stream) {
     WMAR_REQUIRE(logits3_dev && q_dev && scratch_dev && tok_out_dev, "cham_sample: null argument");
     WMAR_REQUIRE(V > 0 && V < (1ll << 31), "cham_sample: bad vocab");
     WMAR_REQUIRE(!(top_p >= 0) || top_p <= 1.0, "`top_p` has to be a float > 0 and < 1, but is %f", top_p);
@@ -579,6 +587,7 @@ int wmar_cham_sample(const wmar_wm_ctx* wm, const float* logits3_dev, int64_t B,
     a.g_image = guidance_scale_image;
     a.allow = allow_dev;
     a.V = V;
+    if (allow_ids_dev && n_allow > 0) { a.gather = allow_ids_dev; a.Vsrc = V; a.V = n_allow; }
     a.past = (const long long*)past_ids_dev;
     a.past_stride = past_stride;
     a.t_host = t;

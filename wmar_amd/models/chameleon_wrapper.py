@@ -85,6 +85,7 @@ class ChameleonARMMWrapper(AutoregressiveMultimodalModelWrapper):
             vq.alive_ids = torch.tensor(self.vocab.image_tokens, dtype=torch.long)
             vq.dead_ids = torch.tensor([t for t in range(cfg.vocab_size) if t not in alive], dtype=torch.long)
         self._allow_img = allow_bitmap(self.vocab.image_tokens, cfg.vocab_size, dev)
+        self._allow_ids = torch.tensor(sorted(self.vocab.image_tokens), dtype=torch.int32, device=dev)
         self.codes_size = vq_cfg.codes_size
         self.image_size = vq_cfg.resolution
         self.dim_z = vq_cfg.z_channels
@@ -177,7 +178,8 @@ class ChameleonARMMWrapper(AutoregressiveMultimodalModelWrapper):
             qq = q[:, b0:b1].contiguous() if q is not None else self.draw_noise(b1 - b0)
             out[b0:b1] = self.model.engine.generate_image(
                 self.split_inputs_for_cfg(prompts[b0:b1]), qq, self.n_image_tokens, gen_params["temperature"], gen_params["top_p"],
-                self.guidance_scale_text, self.guidance_scale_image, allow=self._allow_img, wm_ctx=wm_ctx, use_graph=self.use_graph)
+                self.guidance_scale_text, self.guidance_scale_image, allow=self._allow_img, wm_ctx=wm_ctx, use_graph=self.use_graph,
+                allow_ids=self._allow_ids)
         codes = out.detach().contiguous()
         assert self.is_codes_shaped(codes), f"Codes shape: {codes.shape}"
         return codes

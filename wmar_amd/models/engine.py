@@ -379,9 +379,11 @@ class ChameleonEngine:
 
     def generate_image(self, prompts, q: torch.Tensor, n_tokens: int, temperature: float, top_p: Optional[float],
                        guidance_scale_text: float, guidance_scale_image: float, allow: Optional[torch.Tensor] = None,
-                       wm_ctx: Optional[_lib.WmCtx] = None, use_graph: bool = True) -> torch.Tensor:
+                       wm_ctx: Optional[_lib.WmCtx] = None, use_graph: bool = True,
+                       allow_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
         """prompts: the 3B token lists (full-, image-, un-conditioned, in that order); q float32 [n_tokens, B, V];
-        allow: int32 bitmap [V/32] of permitted vocabulary entries.  Returns int64 [B, n_tokens] vocabulary ids."""
+        allow: int32 bitmap [V/32] of permitted vocabulary entries; allow_ids: the same set as ascending int32 ids (lets the
+        sampler work on the compacted row).  Returns int64 [B, n_tokens] vocabulary ids."""
         _require_cuda(q, "q")
         M = len(prompts)
         assert M % 3 == 0
@@ -396,9 +398,13 @@ class ChameleonEngine:
         if allow is not None:
             _require_cuda(allow, "allow bitmap")
             assert allow.dtype == torch.int32 and allow.numel() == V // 32 and allow.is_contiguous()
+        if allow_ids is not None:
+            _require_cuda(allow_ids, "allow ids")
+            assert allow is not None and allow_ids.dtype == torch.int32 and allow_ids.is_contiguous()
         with torch.cuda.device(self.device):
             _lib.check(self._L.wmar_cham_generate_image(
                 self._h, C.byref(wm_ctx) if wm_ctx is not None else None, flat.ctypes.data, lens.ctypes.data, B, C.byref(sp),
-                allow.data_ptr() if allow is not None else None, q.data_ptr(), int(n_tokens), out.data_ptr(),
+                allow.data_ptr() if allow is not None else None, allow_ids.data_ptr() if allow_ids is not None else None,
+                int(allow_ids.numel()) if allow_ids is not None else 0, q.data_ptr(), int(n_tokens), out.data_ptr(),
                 _lib.stream_ptr(self.device)))
         return out
