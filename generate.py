@@ -1,6 +1,6 @@
 """CLI of the reference's ``generate.py`` (generate.py:235-426) for the MI355X build.
 
-Same flags; `--model taming` only (RAR / Chameleon are later rows of the scope table).
+Same flags and model dispatch (`--model taming | rar | chameleon7b`, generate.py:319-327 of the reference).
 Launch one process per GPU to shard the batches the way the reference's
 ``--chunk_id/--num_chunks`` job array does:
 
@@ -60,13 +60,15 @@ def main():
     sys.path.append(os.getcwd())
     args, _ = get_parser().parse_known_args()
     assert args.outdir, "Output directory is not set"
-    assert args.model == "taming", "this build covers --model taming (see DESIGN.md for the scope table)"
+    assert args.model in ("taming", "rar", "chameleon7b"), f"Model {args.model} not supported"
     assert not args.sync, "--sync (WAM/SyncSeal) is outside the MI355X hot path"
     os.makedirs(args.outdir, exist_ok=True)
 
     import torch.distributed as dist
 
     from wmar_amd import harness
+    from wmar_amd.models.chameleon_wrapper import ChameleonARMMWrapper
+    from wmar_amd.models.rar_wrapper import RarARMMWrapper
     from wmar_amd.models.taming_wrapper import TamingARMMWrapper
     from wmar_amd.utils import synth
     from wmar_amd.utils.utils import update_weights
@@ -83,18 +85,44 @@ def main():
     harness.seed_everything(args.seed, chunk_id)
 
     device = f"cuda:{local_rank}"
-    if args.synthetic:
-        model = TamingARMMWrapper.synthetic(synth.TAMING_GPT, synth.TAMING_VQ, seed=0, device=device,
-                                            max_batch=min(args.batch_size, 128))
+    seed = args.seed + 1000 * chunk_id
+    if args.model == "taming":
+        if args.synthetic:
+            model = TamingARMMWrapper.synthetic(synth.TAMING_GPT, synth.TAMING_VQ, seed=0, device=device,
+                                                max_batch=min(args.batch_size, 128))
+        else:
+            model = TamingARMMWrapper(args.modelpath, device=device, max_batch=min(args.batch_size, 128))
+    elif args.model == "rar":
+        if args.synthetic:
+            model = RarARMMWrapper.synthetic(device=device, max_batch=min(args.batch_size, 64))
+        else:
+            model = RarARMMWrapper(args.modelpath, device=device, max_batch=min(args.batch_size, 64))
     else:
-        model = TamingARMMWrapper(args.modelpath, device=device, max_batch=min(args.batch_size, 128))
+        if args.synthetic:
+            model = ChameleonARMMWrapper.synthetic(seed=seed, device=device, max_batch=min(args.batch_size, 16))
+        else:
+            model = ChameleonARMMWrapper(args.modelpath, seed, device=device, max_batch=min(args.batch_size, 16))
     if args.encoder_ft_ckpt is not None and args.encoder_ft_ckpt != "none":
+        assert args.model == "taming", "delta checkpoints are wired for the Taming VQGAN only"
         update_weights(model, "encoder", args.encoder_ft_ckpt)
     if args.decoder_ft_ckpt is not None and args.decoder_ft_ckpt != "none":
+        assert args.model == "taming", "delta checkpoints are wired for the Taming VQGAN only"
         update_weights(model, "decoder", args.decoder_ft_ckpt)
 
-    conditionings = [int(c) for c in args.conditioning.split(",")]
+    if ".txt" in args.conditioning:      # file with prompts (Chameleon): (index, prompt) tuples
+        with open(args.conditioning, "r") as f:
+            conditionings = [(idx, line.strip()) for idx, line in enumerate(f)]
+    else:                                # ImageNet classes
+        conditionings = [int(c) for c in args.conditioning.split(",")]
+    if args.model == "chameleon7b" and conditionings and isinstance(conditionings[0], int):
+        # no prompt file: synthetic prompts (lists of text-token ids derived from the integer) so that --synthetic runs need no tokenizer
+        text = model.vocab.text_tokens
+        conditionings = [(c, [text[(c * 37 + j * 11) % len(text)] for j in range(12 + c % 5)]) for c in conditionings]
     all_inputs = [c for c in conditionings for _ in range(args.num_samples_per_conditioning)]
+    if "chameleon" in args.model or "rar" in args.model:
+        assert (args.wm_method in ["none", "gentime"] and args.wm_seed_strategy in ["linear", "fixed"]
+                and args.wm_split_strategy == "stratifiedrand"), \
+            "Chameleon and RAR models only support none or gentime watermarking with fixed/linear seed and stratifiedrand split"
 
     vocab_size = model.get_total_vocab_size()
     watermarker = None
