@@ -8,7 +8,7 @@ B = 64
 cfg = synth.TAMING_GPT
 sd = synth.synth_gpt_state_fast(cfg, 0, "cuda", logit_scale=30.0)
 eng = GPTEngine(cfg, sd, max_batch=B); del sd
-for kv in (16, 64, 128, 192, 256):
+for kv in (1, 16, 64, 128, 192, 256):
     us = eng.profile_role("attn", B, kv_len=kv, iters=96)
     gb = 2.0 * B * cfg.n_embd * 4 * kv / 1e9
     print(f"attn kv={kv:3d}: {us:7.2f} us  {gb/us*1e3:6.2f} TB/s")
