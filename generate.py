@@ -53,6 +53,8 @@ def get_parser():
     parser.add_argument("--syncpath", type=str)
     parser.add_argument("--seed", type=int, nargs="?", help="seed", default=42)
     parser.add_argument("--synthetic", type=str2bool, default=False, help="random-init weights instead of checkpoints")
+    parser.add_argument("--augmentations", type=str2bool, default=True,
+                        help="run the classic robustness transforms (blur, noise, jpeg, brightness, rotation, flip, crop)")
     return parser
 
 
@@ -143,11 +145,15 @@ def main():
             watermarker.set_key_table(table)
     model.set_watermarker(watermarker)
 
-    # robustness attacks (augmentations, neural codecs, DiffPure) are outside the hot path
+    # evaluation transforms: the classic ones run batched on the GPU; neural codecs and DiffPure are outside this build
     if args.orig_only:
         eval_params = {"metric_names": [], "augmentations": [], "max_roundtrips": 0, "orig_only": True}
     else:
-        eval_params = {"metric_names": ["pvalue", "l0", "psnr"], "augmentations": [], "max_roundtrips": 1,
+        from wmar_amd.augmentations import AugmentationManager
+        if args.include_neural_compress or args.include_diffpure:
+            print("WARNING: neural-compression / DiffPure attacks are not part of this build and are skipped", file=sys.stderr)
+        augs = AugmentationManager(False, False, load_augs=True).augs if args.augmentations else []
+        eval_params = {"metric_names": ["pvalue", "l0", "psnr"], "augmentations": augs, "max_roundtrips": 1,
                        "orig_only": False}
     gen_params = {"batch_size": args.batch_size, "temperature": args.temperature, "top_k": args.top_k,
                   "top_p": args.top_p}

@@ -46,8 +46,8 @@ def seed_everything(seed: int, chunk_id: int = 0):
 
 @torch.no_grad()
 def fill_batch_log(batch_log, key, model, codes, eval_params, sync_manager=None):
-    """generate.py:112-164 without the synchronization layer and the augmentation sweep
-    (both outside the hot path): decode, then `max_roundtrips` encode->decode round trips."""
+    """generate.py:112-164 without the synchronization layer: decode, `max_roundtrips` encode->decode round trips, then
+    every (transform, parameter) of the augmentation table on the WHOLE batch (one re-encode launch sequence per parameter)."""
     assert sync_manager is None, "the WAM/SyncSeal layer is outside the MI355X hot path"
     imgs = model.codes_to_images(codes)  # [b, 3, R, R] in [-1, 1]
     batch_log[key] = {}
