@@ -1,63 +1,72 @@
-"""Mirror of ``wmar.models.armm_wrapper`` (wmar/models/armm_wrapper.py:22-89): the abstract
-wrapper API the harness and notebooks talk to.  Only the parts on the generation/detection
-path are kept; ``load_model`` (VQGAN loader for finetuning) is out of scope."""
+"""The wrapper contract the harness and notebooks talk to -- same method names, arguments and shape rules as
+``wmar.models.armm_wrapper.AutoregressiveMultimodalModelWrapper`` (wmar/models/armm_wrapper.py:22-89).  ``load_model``
+(a VQGAN loader for finetuning) is not part of the generation/detection path."""
 from __future__ import annotations
 
 import torch
 
 
+def _read_id_list(path):
+    """Comma-separated ids, possibly over several lines, in FILE order."""
+    ids = []
+    with open(path, "r") as f:
+        for line in f:
+            ids += [int(tok) for tok in line.split(",") if tok.strip()]
+    return ids
+
+
 class AutoregressiveMultimodalModelWrapper:
+    """Subclasses set ``model`` (with a ``device``), ``codes_size``, ``image_size`` and implement the abstract methods."""
+
+    _ABSTRACT = "Subclass should implement this"
+
     def __init__(self):
         pass
 
+    # ---- what a model wrapper must provide
     def set_watermarker(self, watermarker=None):
-        raise NotImplementedError("Subclass should implement this, after init")
+        raise NotImplementedError(self._ABSTRACT + ", after init")
 
     def get_image_tokenizer(self):
-        raise NotImplementedError("Subclass should implement this")
+        raise NotImplementedError(self._ABSTRACT)
 
     def get_vq(self):
-        raise NotImplementedError("Subclass should implement this")
+        raise NotImplementedError(self._ABSTRACT)
 
     def get_total_vocab_size(self):
-        raise NotImplementedError("Subclass should implement this")
+        raise NotImplementedError(self._ABSTRACT)
+
+    def sample(self, conditioning, gen_params, apply_watermark=False):
+        raise NotImplementedError(self._ABSTRACT)
+
+    def codes_to_images(self, codes):
+        raise NotImplementedError(self._ABSTRACT)
+
+    def images_to_codes(self, images):
+        raise NotImplementedError(self._ABSTRACT)
 
     @property
     def device(self):
         return self.model.device
 
     def init_alivecodes(self, alive_ids_path):
-        """armm_wrapper.py:42-55 -- alive ids in FILE order, dead = list(set(range(V)) - set(alive))."""
+        """Attach ``alive_ids`` (file order) and ``dead_ids`` to the quantizer.  The dead list is
+        ``list(set(range(V)) - set(alive))`` exactly as armm_wrapper.py:42-55 builds it: its ORDER feeds the key derivation."""
         vq = self.get_image_tokenizer().quantize
-        vocab_sz = vq.n_e if hasattr(vq, "n_e") else vq.num_embeddings
-        alive_ids = []
-        with open(alive_ids_path, "r") as f:
-            for line in f:
-                alive_ids.extend(list(map(int, line.split(","))))
-        dead_ids = list(set(range(vocab_sz)) - set(alive_ids))
-        vq.alive_ids = torch.tensor(alive_ids, dtype=torch.long)
-        vq.dead_ids = torch.tensor(dead_ids, dtype=torch.long)
+        vocab = getattr(vq, "n_e", None)
+        if vocab is None:
+            vocab = vq.num_embeddings
+        alive = _read_id_list(alive_ids_path)
+        dead = list(set(range(vocab)) - set(alive))
+        vq.alive_ids = torch.tensor(alive, dtype=torch.long)
+        vq.dead_ids = torch.tensor(dead, dtype=torch.long)
 
-    def sample(self, conditioning, gen_params, apply_watermark=False):
-        raise NotImplementedError("Subclass should implement this")
-
-    def codes_to_images(self, codes):
-        raise NotImplementedError("Subclass should implement this")
-
-    def images_to_codes(self, images):
-        raise NotImplementedError("Subclass should implement this")
-
-    # Shape checkers
+    # ---- shape rules
     def is_codes_shaped(self, codes):
-        return (
-            isinstance(codes, torch.Tensor) and codes.ndim == 2 and codes.shape[1] == self.codes_size * self.codes_size
-        )
+        n = self.codes_size * self.codes_size
+        return isinstance(codes, torch.Tensor) and codes.ndim == 2 and codes.shape[1] == n
 
     def is_images_shaped(self, images):
-        return (
-            isinstance(images, torch.Tensor)
-            and images.ndim == 4
-            and images.shape[1] == 3
-            and images.shape[2] == self.image_size
-            and images.shape[3] == self.image_size
-        )
+        if not isinstance(images, torch.Tensor) or images.ndim != 4:
+            return False
+        return tuple(images.shape[1:]) == (3, self.image_size, self.image_size)
