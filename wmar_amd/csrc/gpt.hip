@@ -419,8 +419,11 @@ int wmar_gpt_profile_role(wmar_gpt* g, int32_t role, int64_t B, int32_t kv_len, 
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, g->pos_dev, (int)kv_len - 1);
     StepIO io{g->past, (long long)g->Tmax + 1, 0, g->logits};
     StepPlan p(g, B, io, st);
+    // dev knob: WMAR_PROFILE_LAYERS=n cycles through the first n layers only (n = 1: weights stay in the memory-side cache)
+    const char* pl = getenv("WMAR_PROFILE_LAYERS");
+    const int ncycle = pl && atoi(pl) > 0 ? std::min(atoi(pl), g->L) : g->L;
     auto one = [&](int it) -> int {
-        const int l = it % g->L;
+        const int l = it % ncycle;
         switch (role) {
             case WMAR_T_EMBED: return p.embed();
             case WMAR_T_QKV: return p.qkv(l);
