@@ -23,7 +23,7 @@ def _close(got, ref, frac):
     assert float((got - ref).abs().mean()) <= 0.25 * frac * scale
 
 
-@pytest.mark.parametrize("hd,kv,qk,M", [(64, None, True, 5), (128, None, True, 48), (64, 2, False, 33), (128, 1, True, 96)])
+@pytest.mark.parametrize("hd,kv,qk,M", [(64, None, True, 5), (128, None, True, 48), (64, 2, False, 33), (128, 1, True, 96), (64, 4, True, 120)])
 def test_forward_tokens_vs_oracle(hd, kv, qk, M):
     from wmar_amd.models.engine import ChameleonEngine
     cfg = _cfg(hd=hd, kv=kv, qk=qk, dim=256 if hd == 64 else 512)
