@@ -169,6 +169,9 @@ def main():
     if chunk_id == 0 or world == 1:
         with open(os.path.join(args.outdir, "results.json"), "w") as f:
             json.dump(recs, f)
+        from wmar_amd.utils.analyzer import summarize
+        with open(os.path.join(args.outdir, "summary.json"), "w") as f:      # TPR@1%FPR, mean l0 / PSNR per (method, transform, param)
+            json.dump(summarize(recs), f, indent=1)
     print("Done.")
 
 
