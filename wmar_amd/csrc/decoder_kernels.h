@@ -332,13 +332,28 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
     } else {
         WMAR_LN_PROLOGUE
     }
-    for (; kb < kb1; ++kb) {  // tail (slices that are not a multiple of 2U blocks)
-        float4 wv = ld_nt(Wp + (long long)kb * 64);
-        float4 xt[MTW];
+    // tail (slices that are not a multiple of 2U blocks, at most 2U-1 of them): every load is issued before the
+    // first wait -- one k-block at a time would expose a full memory round trip per block
+    if (kb < kb1) {
+        const int nt_ = kb1 - kb;
 #pragma unroll
-        for (int i = 0; i < MTW; ++i) xt[i] = Xp[(long long)kb * xstep + i * 64];
-        WMAR_LNX(xt)
-        WMAR_MMA1(wv, xt)
+        for (int u = 0; u < U; ++u) {
+            const int ka = min(kb + u, kb1 - 1), kbb = min(kb + U + u, kb1 - 1);
+            wA[u] = ld_nt(Wp + (long long)ka * 64);
+            wB[u] = ld_nt(Wp + (long long)kbb * 64);
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+                xA[u][i] = Xp[(long long)ka * xstep + i * 64];
+                xB[u][i] = Xp[(long long)kbb * xstep + i * 64];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (u < nt_) { WMAR_LNX(xA[u]) WMAR_MMA1(wA[u], xA[u]) }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (U + u < nt_) { WMAR_LNX(xB[u]) WMAR_MMA1(wB[u], xB[u]) }
     }
 #undef WMAR_MMA1
 #undef WMAR_LNX
