@@ -337,16 +337,19 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
     if (kb < kb1) {
         const int nt_ = kb1 - kb;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int ka = min(kb + u, kb1 - 1), kbb = min(kb + U + u, kb1 - 1);
-            wA[u] = ld_nt(Wp + (long long)ka * 64);
-            wB[u] = ld_nt(Wp + (long long)kbb * 64);
+        for (int u = 0; u < U; ++u)
+            if (u < nt_) {             // wave-uniform: only the blocks that exist are fetched
+                wA[u] = ld_nt(Wp + (long long)(kb + u) * 64);
 #pragma unroll
-            for (int i = 0; i < MTW; ++i) {
-                xA[u][i] = Xp[(long long)ka * xstep + i * 64];
-                xB[u][i] = Xp[(long long)kbb * xstep + i * 64];
+                for (int i = 0; i < MTW; ++i) xA[u][i] = Xp[(long long)(kb + u) * xstep + i * 64];
             }
-        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (U + u < nt_) {
+                wB[u] = ld_nt(Wp + (long long)(kb + U + u) * 64);
+#pragma unroll
+                for (int i = 0; i < MTW; ++i) xB[u][i] = Xp[(long long)(kb + U + u) * xstep + i * 64];
+            }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < U; ++u)
