@@ -112,39 +112,50 @@ static __global__ __launch_bounds__(256) void k_modulate(ModArgs a) {
     const int kb0 = (int)((unsigned)c * (unsigned)a.KB / (unsigned)a.n_chunks);
     const int kb1 = (int)((unsigned)(c + 1) * (unsigned)a.KB / (unsigned)a.n_chunks);
     const int m = mt * 32 + (lane & 31), half = lane >> 5;
+    const bool shared = a.shift_u && m >= a.split;
+    const long long mrow = shared ? (long long)(*a.pos_dev) * a.mod_stride : (long long)m * a.mod_stride;
+    const float* scale = (shared ? a.scale_u : a.scale) + mrow;
+    const float* shift = (shared ? a.shift_u : a.shift) + mrow;
+    // every load of this wave's (up to) four k-blocks is issued before the first use: one round trip, not four
+    constexpr int KPW = 4;   // the host keeps chunks at <= 16 k-blocks (stat_chunks)
+    float4 v[KPW], g4[KPW], b4[KPW], sc[KPW], sh[KPW];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        const int kb = min(kb0 + w + 4 * i, kb1 - 1);
+        const int k = kb * 8 + 4 * half;
+        v[i] = a.x[((long long)kb * a.MT + mt) * 64 + lane];
+        g4[i] = a.gamma ? *(const float4*)(a.gamma + k) : make_float4(1.f, 1.f, 1.f, 1.f);
+        b4[i] = a.gamma ? *(const float4*)(a.beta + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sc[i] = *(const float4*)(scale + k);
+        sh[i] = *(const float4*)(shift + k);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // the row statistics are fetched while the data loads are in flight
     float mu, rstd;
     {   // eps 1e-6 (RAR's norm_layer); ln_row_stats uses 1e-5, so finish the statistics here
         double sm = 0, sq = 0;
         for (int c0 = 0; c0 < a.n_chunks; c0 += 16) {
-            double2 v[16];
+            double2 st[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = *(const double2*)(a.stats + ((long long)min(c0 + i, a.n_chunks - 1) * a.MT * 32 + m) * 2);
+            for (int i = 0; i < 16; ++i) st[i] = *(const double2*)(a.stats + ((long long)min(c0 + i, a.n_chunks - 1) * a.MT * 32 + m) * 2);
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                if (c0 + i < a.n_chunks) { sm += v[i].x; sq += v[i].y; }
+                if (c0 + i < a.n_chunks) { sm += st[i].x; sq += st[i].y; }
         }
         const double invK = 1.0 / (double)a.K;
         const double mean = sm * invK;
         mu = (float)mean;
         rstd = rsqrtf((float)(sq * invK - mean * mean) + 1e-6f);
     }
-    const bool shared = a.shift_u && m >= a.split;
-    const long long mrow = shared ? (long long)(*a.pos_dev) * a.mod_stride : (long long)m * a.mod_stride;
-    const float* scale = (shared ? a.scale_u : a.scale) + mrow;
-    const float* shift = (shared ? a.shift_u : a.shift) + mrow;
-    for (int kb = kb0 + w; kb < kb1; kb += 4) {
-        const int k = kb * 8 + 4 * half;
-        const long long idx = ((long long)kb * a.MT + mt) * 64 + lane;
-        const float4 v = a.x[idx];
-        float r[4] = {(v.x - mu) * rstd, (v.y - mu) * rstd, (v.z - mu) * rstd, (v.w - mu) * rstd};
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        const int kb = kb0 + w + 4 * i;
+        if (kb >= kb1) continue;
+        float r[4] = {(v[i].x - mu) * rstd, (v[i].y - mu) * rstd, (v[i].z - mu) * rstd, (v[i].w - mu) * rstd};
         if (a.gamma) {
-            const float4 g = *(const float4*)(a.gamma + k), bt = *(const float4*)(a.beta + k);
-            r[0] = r[0] * g.x + bt.x; r[1] = r[1] * g.y + bt.y; r[2] = r[2] * g.z + bt.z; r[3] = r[3] * g.w + bt.w;
+            r[0] = r[0] * g4[i].x + b4[i].x; r[1] = r[1] * g4[i].y + b4[i].y; r[2] = r[2] * g4[i].z + b4[i].z; r[3] = r[3] * g4[i].w + b4[i].w;
         }
-        const float4 sc = *(const float4*)(scale + k);
-        const float4 sh = *(const float4*)(shift + k);
-        a.h[idx] = make_float4(r[0] * (1.0f + sc.x) + sh.x, r[1] * (1.0f + sc.y) + sh.y, r[2] * (1.0f + sc.z) + sh.z,
-                               r[3] * (1.0f + sc.w) + sh.w);
+        a.h[((long long)kb * a.MT + mt) * 64 + lane] = make_float4(r[0] * (1.0f + sc[i].x) + sh[i].x, r[1] * (1.0f + sc[i].y) + sh[i].y,
+                                                                r[2] * (1.0f + sc[i].z) + sh[i].z, r[3] * (1.0f + sc[i].w) + sh[i].w);
     }
 }
 
