@@ -324,7 +324,18 @@ static __global__ __launch_bounds__(256) void k_cham_swiglu(SwigluArgs a) {
     // grid: (ceil(NT / 4), MT); the four waves take four consecutive tiles of one row tile
     __shared__ double red[8][32];
     const int mt = blockIdx.y, lane = threadIdx.x & 63;
-    const int nt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nt = min(blockIdx.x * 4 + (int)(threadIdx.x >> 6), a.NT - 1);
+    const bool live = blockIdx.x * 4 + (int)(threadIdx.x >> 6) < a.NT;
+    const int g = nt / BG_TG, np = sk_count(a.sk, g);
+    const long long i1 = ((((long long)nt * 2) * a.MT + mt) * 64 + lane) * 8, i3 = ((((long long)nt * 2 + 1) * a.MT + mt) * 64 + lane) * 8;
+    // the first four pieces are requested before the row statistics: both arrive in one round trip
+    float4 a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const long long po = (long long)min(d, np - 1) * a.slab_stride;
+        a0[d] = *(const float4*)(a.slabs + po + i1); a1[d] = *(const float4*)(a.slabs + po + i1 + 4);
+        b0[d] = *(const float4*)(a.slabs + po + i3); b1[d] = *(const float4*)(a.slabs + po + i3 + 4);
+    }
     {   // 1/rms of the 32 rows: 8 thread groups x (n_chunks / 8) statistics chunks each
         const int r = threadIdx.x & 31, grp = threadIdx.x >> 5;
         double ssum = 0;
@@ -332,23 +343,22 @@ static __global__ __launch_bounds__(256) void k_cham_swiglu(SwigluArgs a) {
         red[grp][r] = ssum;
     }
     __syncthreads();
-    if (nt >= a.NT) return;
+    if (!live) return;
     double tot = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) tot += red[i][lane & 31];
     const float rstd = rsqrtf((float)(tot / (double)a.K) + a.eps);
-    const int g = nt / BG_TG, np = sk_count(a.sk, g);
     float x1[8], x3[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { x1[j] = 0.f; x3[j] = 0.f; }
-    const long long i1 = ((((long long)nt * 2) * a.MT + mt) * 64 + lane) * 8, i3 = ((((long long)nt * 2 + 1) * a.MT + mt) * 64 + lane) * 8;
     for (int s0 = 0; s0 < np; s0 += 4) {        // four pieces per round trip
-        float4 a0[4], a1[4], b0[4], b1[4];
+        if (s0 > 0) {
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const long long po = (long long)min(s0 + d, np - 1) * a.slab_stride;
-            a0[d] = *(const float4*)(a.slabs + po + i1); a1[d] = *(const float4*)(a.slabs + po + i1 + 4);
-            b0[d] = *(const float4*)(a.slabs + po + i3); b1[d] = *(const float4*)(a.slabs + po + i3 + 4);
+            for (int d = 0; d < 4; ++d) {
+                const long long po = (long long)min(s0 + d, np - 1) * a.slab_stride;
+                a0[d] = *(const float4*)(a.slabs + po + i1); a1[d] = *(const float4*)(a.slabs + po + i1 + 4);
+                b0[d] = *(const float4*)(a.slabs + po + i3); b1[d] = *(const float4*)(a.slabs + po + i3 + 4);
+            }
         }
 #pragma unroll
         for (int d = 0; d < 4; ++d)
