@@ -50,17 +50,26 @@ struct wmar_gpt {
     int *pos_dev = nullptr, *step_dev = nullptr;
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
+    // One captured step per attention phase: the decode attention runs 1 / 2 / 4 waves per (sequence, head) while the
+    // cache is short / medium / long (att_phase(): fixed cost 7.0 / 9.8 / 13.5 us against loads in flight).
+    static constexpr int N_PHASE = 3;
+    hipGraph_t graph[N_PHASE] = {nullptr, nullptr, nullptr};
+    hipGraphExec_t exec[N_PHASE] = {nullptr, nullptr, nullptr};
+    int att_nw = 2;                // waves per attention workgroup of the step being enqueued
     unsigned long long graph_key[12] = {0};
     bool pending = false;          // replays of `exec` may still be running (ev1 marks their end)
     void drop_graph() {
         if (pending && ev1) (void)hipEventSynchronize(ev1);
         pending = false;
-        if (exec) (void)hipGraphExecDestroy(exec);
-        if (graph) (void)hipGraphDestroy(graph);
-        exec = nullptr; graph = nullptr;
+        for (int i = 0; i < N_PHASE; ++i) {
+            if (exec[i]) (void)hipGraphExecDestroy(exec[i]);
+            if (graph[i]) (void)hipGraphDestroy(graph[i]);
+            exec[i] = nullptr; graph[i] = nullptr;
+        }
     }
+    // phase of the step that attends to `kv` cached rows (including the new one)
+    static int att_phase(int kv) { return kv <= 112 ? 0 : (kv <= 208 ? 1 : 2); }
+    static int phase_waves(int ph) { return ph == 0 ? 1 : (ph == 1 ? 2 : 4); }
     int timing = 0;
     int force_s[3] = {0, 0, 0};   // tuning knobs: WMAR_S_QKV / WMAR_S_PROJ / WMAR_S_FC2
     double step_ms = 0.0;
@@ -201,7 +210,7 @@ struct StepPlan {
         t.kcache = g->kcache + l * lstride; t.vcache = g->vcache + l * lstride; t.y = g->y; t.pos_dev = g->pos_dev;
         t.D = D; t.H = g->H; t.Tmax = g->Tmax; t.MT = MT; t.scale = 1.0f / sqrtf((float)g->hd);
         { const char* e = getenv("WMAR_ATT_DBG"); t.dbg = e ? atoi(e) : 0; }
-        int nwa = 2;   // measured best at the average cache length (kv=128)
+        int nwa = g->att_nw;   // chosen per phase by the caller (generate / profile_role); WMAR_ATT_NW pins it
         { const char* e = getenv("WMAR_ATT_NW"); if (e) nwa = atoi(e); }
         const dim3 grid((unsigned)(B * g->H));
         g->span_begin(WMAR_T_ATTN, st);
@@ -407,6 +416,7 @@ int wmar_gpt_decode_step(wmar_gpt* g, const int64_t* tok_dev, int64_t B, int32_t
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, g->pos_dev, (int)pos);
     StepIO io{(const long long*)tok_dev, 1, 0, logits_dev};
+    g->att_nw = wmar_gpt::phase_waves(wmar_gpt::att_phase(pos + 1));
     return enqueue_step(g, B, io, st);
 }
 
@@ -418,6 +428,7 @@ int wmar_gpt_profile_role(wmar_gpt* g, int32_t role, int64_t B, int32_t kv_len, 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, g->pos_dev, (int)kv_len - 1);
     StepIO io{g->past, (long long)g->Tmax + 1, 0, g->logits};
+    g->att_nw = wmar_gpt::phase_waves(wmar_gpt::att_phase(kv_len));
     StepPlan p(g, B, io, st);
     // dev knob: WMAR_PROFILE_LAYERS=n cycles through the first n layers only (n = 1: weights stay in the memory-side cache)
     const char* pl = getenv("WMAR_PROFILE_LAYERS");
@@ -500,7 +511,8 @@ int wmar_gpt_generate(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_para
     a.t_dev = len_dev;
 
     StepIO io{g->past, pstride, 1, g->logits};
-    auto one_step = [&](hipStream_t s) -> int {
+    auto one_step = [&](hipStream_t s, int phase) -> int {
+        g->att_nw = wmar_gpt::phase_waves(phase);
         int rc = enqueue_step(g, B, io, s);
         if (rc) return rc;
         g->span_begin(WMAR_T_SAMPLE, s);
@@ -523,19 +535,21 @@ int wmar_gpt_generate(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_para
                                       0ull, 0ull, (unsigned long long)sp->top_k, 0ull};
         float fd = wm ? wm->delta : 0.f, ft = sp->temperature;
         memcpy(&key[8], &fd, 4); memcpy(&key[9], &ft, 4); memcpy(&key[11], &sp->top_p, 8);
-        if (g->exec && memcmp(key, g->graph_key, sizeof(key)) != 0) g->drop_graph();
-        if (!g->exec) {
-            WMAR_HIP_CHECK(hipStreamBeginCapture(g->cap_stream, hipStreamCaptureModeThreadLocal));
-            int rc = one_step(g->cap_stream);
-            hipError_t e = hipStreamEndCapture(g->cap_stream, &g->graph);
-            if (rc) { g->drop_graph(); return rc; }
-            if (e != hipSuccess) { g->drop_graph(); set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return WMAR_EHIP; }
-            e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
-            if (e != hipSuccess) { g->drop_graph(); set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return WMAR_EHIP; }
+        if (g->exec[0] && memcmp(key, g->graph_key, sizeof(key)) != 0) g->drop_graph();
+        if (!g->exec[0]) {
+            for (int ph = 0; ph < wmar_gpt::N_PHASE; ++ph) {
+                WMAR_HIP_CHECK(hipStreamBeginCapture(g->cap_stream, hipStreamCaptureModeThreadLocal));
+                int rc = one_step(g->cap_stream, ph);
+                hipError_t e = hipStreamEndCapture(g->cap_stream, &g->graph[ph]);
+                if (rc) { g->drop_graph(); return rc; }
+                if (e != hipSuccess) { g->drop_graph(); set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return WMAR_EHIP; }
+                e = hipGraphInstantiate(&g->exec[ph], g->graph[ph], nullptr, nullptr, 0);
+                if (e != hipSuccess) { g->drop_graph(); set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return WMAR_EHIP; }
+            }
             memcpy(g->graph_key, key, sizeof(key));
         }
         hipError_t e = hipSuccess;
-        for (int n = 0; n < steps && e == hipSuccess; ++n) e = hipGraphLaunch(g->exec, st);
+        for (int n = 0; n < steps && e == hipSuccess; ++n) e = hipGraphLaunch(g->exec[wmar_gpt::att_phase(n + 1)], st);
         if (e == hipSuccess) e = hipEventRecord(g->ev1, st);   // also marks "replays finished" for drop_graph()
         if (e == hipSuccess) { g->pending = true; }
         if (e != hipSuccess) { set_error("graph replay failed: %s", hipGetErrorString(e)); return WMAR_EHIP; }
@@ -544,7 +558,7 @@ int wmar_gpt_generate(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_para
     } else {
         g->span_on = g->timing != 0;
         int rc = WMAR_OK;
-        for (int n = 0; n < steps && rc == WMAR_OK; ++n) rc = one_step(st);
+        for (int n = 0; n < steps && rc == WMAR_OK; ++n) rc = one_step(st, wmar_gpt::att_phase(n + 1));
         g->span_on = false;
         if (rc) return rc;
         if (g->timing) {
