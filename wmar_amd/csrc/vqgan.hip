@@ -68,6 +68,7 @@ struct ConvArgs {
     int CT, KBc;         // cout tiles of 32; cin blocks of 8
     int ks, stride, up, pad;  // pad = leading pad (1 for 3x3 stride 1, 0 otherwise)
     int tiles_x, tiles_y;     // 8x8 output tiles per image
+    int dbuf;                 // double-buffered patch staging (host: full 32-channel rounds, patch <= 4 float4 per thread)
 };
 
 constexpr int CONV_CCH = 32;          // input channels staged per LDS round
@@ -104,6 +105,80 @@ __global__ __launch_bounds__(COT * 64) void k_conv(ConvArgs a) {
     const int prow = j >> 3, pcol = j & 7;
     const float* inb = a.in + (long long)b * a.Hs * a.Ws * a.Cin;
 
+    // one 32-channel round: 9 taps x 4 k-blocks x 8 MFMAs per wave out of the staged patch
+#define WMAR_CONV_ROUND(PATCH, C0, CCH)                                                                         \
+    if (active) {                                                                                               \
+        const int nkb = (CCH) >> 3;                                                                             \
+        const float4* wbase = a.wp + ((long long)ct * T * a.KBc + ((C0) >> 3)) * 64 + lane;                     \
+        for (int tap = 0; tap < T; ++tap) {                                                                     \
+            const int dy = tap / a.ks, dx = tap - dy * a.ks;                                                    \
+            const float4* wt = wbase + (long long)tap * a.KBc * 64;                                             \
+            const float* p0 = (PATCH) + (((prow)*a.stride + dy) * PW + pcol * a.stride + dx) * CONV_PSTRIDE + half * 4; \
+            const float* p1 = p0 + 4 * a.stride * PW * CONV_PSTRIDE;                                            \
+            _Pragma("unroll 4") for (int kb = 0; kb < nkb; ++kb) {                                              \
+                const float4 wv = wt[kb * 64];                                                                  \
+                const float4 x0 = *(const float4*)(p0 + kb * 8);                                                \
+                const float4 x1 = *(const float4*)(p1 + kb * 8);                                                \
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, x0.x, acc[0], 0, 0, 0);                     \
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, x1.x, acc[1], 0, 0, 0);                     \
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, x0.y, acc[0], 0, 0, 0);                     \
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, x1.y, acc[1], 0, 0, 0);                     \
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, x0.z, acc[0], 0, 0, 0);                     \
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, x1.z, acc[1], 0, 0, 0);                     \
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, x0.w, acc[0], 0, 0, 0);                     \
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, x1.w, acc[1], 0, 0, 0);                     \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
+    // Double-buffered staging (the common case: full 32-channel rounds whose patch is at most 4 float4 per thread): the next
+    // round's patch is fetched into registers while this round's MFMAs run and lands in the other LDS buffer afterwards --
+    // one barrier per round and no exposed global-load latency.  a.dbuf is set by the host together with the doubled LDS size.
+    if (a.dbuf) {
+        constexpr int NPT = 4;
+        const int nelem = PH * PW * 8;
+        long long goff[NPT];
+        int loff[NPT];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int e = threadIdx.x + i * COT * 64;
+            goff[i] = -1; loff[i] = -1;
+            if (e < nelem) {
+                const int pix = e >> 3, qq = e & 7;
+                const int py = pix / PW, px = pix - py * PW;
+                int y = iy0 + py, x = ix0 + px;
+                loff[i] = pix * CONV_PSTRIDE + qq * 4;
+                if (y >= 0 && y < Hc && x >= 0 && x < Wc) {
+                    if (a.up) { y >>= 1; x >>= 1; }
+                    goff[i] = ((long long)y * a.Ws + x) * a.Cin + qq * 4;
+                }
+            }
+        }
+        const int psz = PH * PW * CONV_PSTRIDE;
+        float4 pr[NPT];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) pr[i] = goff[i] >= 0 ? *(const float4*)(inb + goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) if (loff[i] >= 0) *(float4*)(patch + loff[i]) = pr[i];
+        __syncthreads();
+        int buf = 0;
+        for (int c0 = 0; c0 < a.Cin; c0 += CONV_CCH) {
+            const bool more = c0 + CONV_CCH < a.Cin;
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < NPT; ++i)
+                    pr[i] = goff[i] >= 0 ? *(const float4*)(inb + goff[i] + c0 + CONV_CCH) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            const float* cur = patch + buf * psz;
+            WMAR_CONV_ROUND(cur, c0, CONV_CCH)
+            if (more) {
+                float* nxt = patch + (buf ^ 1) * psz;
+#pragma unroll
+                for (int i = 0; i < NPT; ++i) if (loff[i] >= 0) *(float4*)(nxt + loff[i]) = pr[i];
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+    } else {
     for (int c0 = 0; c0 < a.Cin; c0 += CONV_CCH) {
         const int cch = min(CONV_CCH, a.Cin - c0);   // multiple of 8
         const int q4 = cch >> 2;                     // float4s per pixel this round
@@ -120,31 +195,10 @@ __global__ __launch_bounds__(COT * 64) void k_conv(ConvArgs a) {
             *(float4*)(patch + pix * CONV_PSTRIDE + qq * 4) = v;
         }
         __syncthreads();
-        if (active) {
-            const int nkb = cch >> 3;
-            const float4* wbase = a.wp + ((long long)ct * T * a.KBc + (c0 >> 3)) * 64 + lane;
-            for (int tap = 0; tap < T; ++tap) {
-                const int dy = tap / a.ks, dx = tap - dy * a.ks;
-                const float4* wt = wbase + (long long)tap * a.KBc * 64;
-                const float* p0 = patch + (((prow)*a.stride + dy) * PW + pcol * a.stride + dx) * CONV_PSTRIDE + half * 4;
-                const float* p1 = p0 + 4 * a.stride * PW * CONV_PSTRIDE;
-#pragma unroll 4
-                for (int kb = 0; kb < nkb; ++kb) {
-                    const float4 wv = wt[kb * 64];
-                    const float4 x0 = *(const float4*)(p0 + kb * 8);
-                    const float4 x1 = *(const float4*)(p1 + kb * 8);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, x0.x, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, x1.x, acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, x0.y, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, x1.y, acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, x0.z, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, x1.z, acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, x0.w, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, x1.w, acc[1], 0, 0, 0);
-                }
-            }
-        }
+        WMAR_CONV_ROUND(patch, c0, cch)
     }
+    }
+#undef WMAR_CONV_ROUND
     if (!active) return;
     // epilogue: lane holds pixel j of each half-tile and couts ct*32 + 8g + 4*half + {0..3}
 #pragma unroll
@@ -606,8 +660,9 @@ int run_conv(const ConvW& c, const float* in, float* out, const float* res, int 
     WMAR_REQUIRE(a.Ho % 8 == 0 && a.Wo % 8 == 0, "conv output %dx%d is not a multiple of the 8x8 tile", a.Ho, a.Wo);
     a.tiles_x = a.Wo / 8; a.tiles_y = a.Ho / 8;
     const int PW = 7 * stride + c.ks;
-    const size_t lds = (size_t)PW * PW * CONV_PSTRIDE * sizeof(float);
     const int COT = c.CT >= 4 ? 4 : (c.CT >= 2 ? 2 : 1);
+    a.dbuf = (c.cin_s % CONV_CCH == 0 && PW * PW * 8 <= 4 * COT * 64) ? 1 : 0;
+    const size_t lds = (size_t)(a.dbuf ? 2 : 1) * PW * PW * CONV_PSTRIDE * sizeof(float);
     const int cgroups = (c.CT + COT - 1) / COT;
     const unsigned grid = (unsigned)((long long)B * cgroups * a.tiles_x * a.tiles_y);
     hipEvent_t e0 = nullptr, e1 = nullptr;
