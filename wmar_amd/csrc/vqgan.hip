@@ -69,7 +69,31 @@ struct ConvArgs {
     int ks, stride, up, pad;  // pad = leading pad (1 for 3x3 stride 1, 0 otherwise)
     int tiles_x, tiles_y;     // 8x8 output tiles per image
     int dbuf;                 // double-buffered patch staging (host: full 32-channel rounds, patch <= 4 float4 per thread)
+    // GroupNorm(32, eps 1e-6) (+ swish) of the INPUT applied while the patch is staged (Normalize + nonlinearity in front of
+    // every conv of a ResnetBlock / AttnBlock / the output conv, model.py:37-39, 104-120): the normalised tensor never exists in HBM
+    const float2* gn_mr;      // nullable: (mean, rstd) per [image][group]
+    const float* gn_g; const float* gn_b;   // per channel
+    int gn_cpg, gn_swish;     // channels per group
 };
+
+__device__ __forceinline__ float4 conv_gn(const ConvArgs& a, float4 v, int b, int c) {
+    const float4 g = *(const float4*)(a.gn_g + c), bt = *(const float4*)(a.gn_b + c);
+    float r[4] = {v.x, v.y, v.z, v.w};
+    const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {bt.x, bt.y, bt.z, bt.w};
+    const float2* mr = a.gn_mr + b * 32;
+    if (a.gn_cpg >= 4 && (a.gn_cpg & 3) == 0) {           // the four channels share a group
+        const float2 m = mr[c / a.gn_cpg];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = (r[i] - m.x) * m.y * gg[i] + bb[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float2 m = mr[(c + i) / a.gn_cpg]; r[i] = (r[i] - m.x) * m.y * gg[i] + bb[i]; }
+    }
+    if (a.gn_swish)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = r[i] / (1.0f + __expf(-r[i]));
+    return make_float4(r[0], r[1], r[2], r[3]);
+}
 
 constexpr int CONV_CCH = 32;          // input channels staged per LDS round
 constexpr int CONV_PSTRIDE = 36;      // floats per staged pixel (32 + 4 pad: spreads LDS banks)
@@ -158,7 +182,11 @@ __global__ __launch_bounds__(COT * 64) void k_conv(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < NPT; ++i) pr[i] = goff[i] >= 0 ? *(const float4*)(inb + goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int i = 0; i < NPT; ++i) if (loff[i] >= 0) *(float4*)(patch + loff[i]) = pr[i];
+        for (int i = 0; i < NPT; ++i)
+            if (loff[i] >= 0) {
+                if (a.gn_mr && goff[i] >= 0) pr[i] = conv_gn(a, pr[i], b, (threadIdx.x + i * COT * 64) % 8 * 4);
+                *(float4*)(patch + loff[i]) = pr[i];
+            }
         __syncthreads();
         int buf = 0;
         for (int c0 = 0; c0 < a.Cin; c0 += CONV_CCH) {
@@ -173,7 +201,11 @@ __global__ __launch_bounds__(COT * 64) void k_conv(ConvArgs a) {
             if (more) {
                 float* nxt = patch + (buf ^ 1) * psz;
 #pragma unroll
-                for (int i = 0; i < NPT; ++i) if (loff[i] >= 0) *(float4*)(nxt + loff[i]) = pr[i];
+                for (int i = 0; i < NPT; ++i)
+                    if (loff[i] >= 0) {
+                        if (a.gn_mr && goff[i] >= 0) pr[i] = conv_gn(a, pr[i], b, c0 + CONV_CCH + (threadIdx.x + i * COT * 64) % 8 * 4);
+                        *(float4*)(nxt + loff[i]) = pr[i];
+                    }
             }
             __syncthreads();
             buf ^= 1;
@@ -191,6 +223,7 @@ __global__ __launch_bounds__(COT * 64) void k_conv(ConvArgs a) {
             if (y >= 0 && y < Hc && x >= 0 && x < Wc) {
                 if (a.up) { y >>= 1; x >>= 1; }
                 v = *(const float4*)(inb + ((long long)y * a.Ws + x) * a.Cin + c0 + qq * 4);
+                if (a.gn_mr) v = conv_gn(a, v, b, c0 + qq * 4);
             }
             *(float4*)(patch + pix * CONV_PSTRIDE + qq * 4) = v;
         }
@@ -272,42 +305,19 @@ __global__ __launch_bounds__(256) void k_gn_partial(GnArgs a) {
     }
 }
 
-// pass 2: y = swish?( (x - mean) * rstd * gamma + beta )
-__global__ __launch_bounds__(256) void k_gn_apply(GnArgs a) {
-    __shared__ float s_mean[32], s_rstd[32];
-    const int b = blockIdx.y;
-    if (threadIdx.x < 32) {
-        double ts = 0, tss = 0;
-        for (int c = 0; c < a.nchunk; ++c) {
-            const double* p = a.partial + (((long long)b * a.nchunk + c) * 32 + threadIdx.x) * 2;
-            ts += p[0]; tss += p[1];
-        }
-        const double n = (double)a.HW * (a.C / 32);
-        const double mean = ts / n;
-        const double var = tss / n - mean * mean;
-        s_mean[threadIdx.x] = (float)mean;
-        s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + 1e-6));
+// pass 2: (mean, rstd) per (image, group) from the partial sums in fixed order; the normalisation itself happens in the
+// consuming conv's patch loader (conv_gn)
+__global__ void k_gn_finalize(GnArgs a, float2* mr) {
+    const int b = blockIdx.x, g = threadIdx.x;
+    double ts = 0, tss = 0;
+    for (int c = 0; c < a.nchunk; ++c) {
+        const double* p = a.partial + (((long long)b * a.nchunk + c) * 32 + g) * 2;
+        ts += p[0]; tss += p[1];
     }
-    __syncthreads();
-    const int q4 = a.C >> 2, cpg = a.C / 32;
-    const long long total = (long long)a.HW * q4;
-    const float* xb = a.x + (long long)b * a.HW * a.C;
-    float* yb = a.y + (long long)b * a.HW * a.C;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const int c = (int)(e % q4) * 4;
-        float4 v = *(const float4*)(xb + e * 4);
-        float4 g = *(const float4*)(a.gamma + c), bt = *(const float4*)(a.beta + c);
-        float r[4] = {v.x, v.y, v.z, v.w};
-        const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {bt.x, bt.y, bt.z, bt.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int grp = (c + i) / cpg;
-            float h = (r[i] - s_mean[grp]) * s_rstd[grp] * gg[i] + bb[i];
-            if (a.swish) h = h / (1.0f + __expf(-h));
-            r[i] = h;
-        }
-        *(float4*)(yb + e * 4) = make_float4(r[0], r[1], r[2], r[3]);
-    }
+    const double n = (double)a.HW * (a.C / 32);
+    const double mean = ts / n;
+    const double var = tss / n - mean * mean;
+    mr[b * 32 + g] = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-6)));
 }
 
 // ------------------------------------------------------------------------ attention (single head)
@@ -563,6 +573,7 @@ struct wmar_vq {
 namespace {
 
 constexpr int GN_CHUNKS_MAX = 64;
+constexpr int GN_MR_DOUBLES = 32768;   // head of the GroupNorm scratch: (mean, rstd) float2 per [image][32 groups], up to 1024 images
 inline int pad8(int c) { return (c + 7) & ~7; }
 
 struct ArenaRef {   // the engine that owns the allocations
@@ -648,9 +659,18 @@ bool in_attn_res(const wmar_vq_config& c, int res) {
 
 static bool vq_trace() { static int v = -1; if (v < 0) { const char* e = getenv("WMAR_VQ_TRACE"); v = e ? atoi(e) : 0; } return v != 0; }
 
+// a GroupNorm whose statistics are ready and whose normalisation is applied by the convs that consume it
+struct GnRef {
+    const float2* mr; const float* g; const float* b; int C, swish;
+};
+
 int run_conv(const ConvW& c, const float* in, float* out, const float* res, int B, int Hs, int Ws, int stride, int up,
-             hipStream_t st) {
+             hipStream_t st, const GnRef* gn = nullptr) {
     ConvArgs a{};
+    if (gn) {
+        WMAR_REQUIRE(gn->C == c.cin_s && !up, "fused GroupNorm: channel count %d != conv input %d", gn->C, c.cin_s);
+        a.gn_mr = gn->mr; a.gn_g = gn->g; a.gn_b = gn->b; a.gn_cpg = gn->C / 32; a.gn_swish = gn->swish;
+    }
     a.in = in; a.wp = c.wp; a.bias = c.bias; a.res = res; a.out = out;
     a.Hs = Hs; a.Ws = Ws; a.Cin = c.cin_s;
     const int Hc = up ? 2 * Hs : Hs, Wc = up ? 2 * Ws : Ws;
@@ -681,20 +701,20 @@ int run_conv(const ConvW& c, const float* in, float* out, const float* res, int 
     return launch_status("k_conv");
 }
 
-int run_gn(double* gn_partial, const NormW& n, const float* x, float* y, int B, int HW, int swish, hipStream_t st) {
+// statistics of GroupNorm(x); the (mean, rstd) table lives behind the partial sums in the same allocation
+int run_gn(double* gn_partial, const NormW& n, const float* x, int B, int HW, int swish, hipStream_t st, GnRef* out) {
     GnArgs a{};
-    a.x = x; a.y = y; a.partial = gn_partial; a.gamma = n.g; a.beta = n.b; a.HW = HW; a.C = n.C; a.swish = swish;
+    a.x = x; a.y = nullptr; a.partial = gn_partial + GN_MR_DOUBLES; a.gamma = n.g; a.beta = n.b; a.HW = HW; a.C = n.C; a.swish = swish;
     WMAR_REQUIRE(n.C % 32 == 0 && n.C / 4 <= 256, "GroupNorm channel count %d unsupported (multiple of 32, <= 1024)", n.C);
     int nchunk = HW / 256;
     if (nchunk < 1) nchunk = 1;
     if (nchunk > GN_CHUNKS_MAX) nchunk = GN_CHUNKS_MAX;
     a.nchunk = nchunk;
     hipLaunchKernelGGL(k_gn_partial, dim3(nchunk, B), dim3(256), 0, st, a);
-    long long total = (long long)HW * (n.C / 4);
-    int gx = (int)((total + 256 * 8 - 1) / (256 * 8));
-    if (gx < 1) gx = 1;
-    if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL(k_gn_apply, dim3(gx, B), dim3(256), 0, st, a);
+    WMAR_REQUIRE(B <= GN_MR_DOUBLES / 32, "GroupNorm: batch %d too large", B);
+    float2* mr = (float2*)gn_partial;
+    hipLaunchKernelGGL(k_gn_finalize, dim3(B), dim3(32), 0, st, a, mr);
+    out->mr = mr; out->g = n.g; out->b = n.b; out->C = n.C; out->swish = swish;
     return launch_status("k_gn");
 }
 
@@ -710,16 +730,17 @@ struct Bufs {
 int run_res(wmar_vq* v, const ResW& r, Bufs& bf, int B, int H, int W, hipStream_t st) {
     int rc;
     float *X = bf.X(), *A = bf.other(1), *T = bf.other(2), *C = bf.other(3);
-    if ((rc = run_gn(v->gn_partial, r.n1, X, A, B, H * W, 1, st))) return rc;
-    if ((rc = run_conv(r.c1, A, T, nullptr, B, H, W, 1, 0, st))) return rc;
-    if ((rc = run_gn(v->gn_partial, r.n2, T, A, B, H * W, 1, st))) return rc;
+    GnRef gn{};
+    if ((rc = run_gn(v->gn_partial, r.n1, X, B, H * W, 1, st, &gn))) return rc;
+    if ((rc = run_conv(r.c1, X, T, nullptr, B, H, W, 1, 0, st, &gn))) return rc;
+    if ((rc = run_gn(v->gn_partial, r.n2, T, B, H * W, 1, st, &gn))) return rc;
     const float* shortcut = X;
     if (r.has_nin) {
         if ((rc = run_conv(r.nin, X, C, nullptr, B, H, W, 1, 0, st))) return rc;
         shortcut = C;
     }
-    if ((rc = run_conv(r.c2, A, T, shortcut, B, H, W, 1, 0, st))) return rc;
-    bf.advance(2);
+    if ((rc = run_conv(r.c2, T, A, shortcut, B, H, W, 1, 0, st, &gn))) return rc;
+    bf.advance(1);
     return WMAR_OK;
 }
 
@@ -727,10 +748,11 @@ int run_attn(wmar_vq* v, const AttnW& w, Bufs& bf, int B, int H, int W, hipStrea
     int rc;
     const int N = H * W, C = w.n.C;
     float *X = bf.X(), *A = bf.other(1), *T = bf.other(2);
-    if ((rc = run_gn(v->gn_partial, w.n, X, A, B, N, 0, st))) return rc;
-    if ((rc = run_conv(w.q, A, v->aq, nullptr, B, H, W, 1, 0, st))) return rc;
-    if ((rc = run_conv(w.k, A, v->ak, nullptr, B, H, W, 1, 0, st))) return rc;
-    if ((rc = run_conv(w.v, A, v->av, nullptr, B, H, W, 1, 0, st))) return rc;
+    GnRef gn{};
+    if ((rc = run_gn(v->gn_partial, w.n, X, B, N, 0, st, &gn))) return rc;
+    if ((rc = run_conv(w.q, X, v->aq, nullptr, B, H, W, 1, 0, st, &gn))) return rc;
+    if ((rc = run_conv(w.k, X, v->ak, nullptr, B, H, W, 1, 0, st, &gn))) return rc;
+    if ((rc = run_conv(w.v, X, v->av, nullptr, B, H, W, 1, 0, st, &gn))) return rc;
     const float scale = 1.0f / sqrtf((float)C);   // int(c)**(-0.5)
     hipLaunchKernelGGL(k_attn_scores, dim3(N, B), dim3(256), (size_t)C * 4, st, v->aq, v->ak, v->asc, N, C, scale);
     hipLaunchKernelGGL(k_attn_pv, dim3(N, B), dim3(256), (size_t)N * 4, st, v->asc, v->av, v->ao, N, C);
@@ -872,7 +894,7 @@ int wmar_vq_create(const wmar_vq_config* cfg, const char* const* names, const vo
     TRY(v->alloc(&v->av, (size_t)v->Bmax * ntok * cam));
     TRY(v->alloc(&v->ao, (size_t)v->Bmax * ntok * cam));
     TRY(v->alloc(&v->asc, (size_t)v->Bmax * ntok * ntok));
-    TRY(v->alloc(&v->gn_partial, (size_t)v->Bmax * GN_CHUNKS_MAX * 32 * 2));
+    TRY(v->alloc(&v->gn_partial, (size_t)GN_MR_DOUBLES + (size_t)v->Bmax * GN_CHUNKS_MAX * 32 * 2));
     TRY(v->alloc(&v->znorm, (size_t)v->Bmax * S * S));
     if (rc == WMAR_OK && hipStreamSynchronize(st) != hipSuccess) { set_error("vq_create: sync failed"); rc = WMAR_EHIP; }
 #undef TRY
@@ -917,8 +939,9 @@ int wmar_vq_decode(wmar_vq* v, const int64_t* codes_dev, int64_t B, float* image
             H *= 2;
         }
     }
-    if ((rc = run_gn(v->gn_partial, v->d_norm_out, bf.X(), bf.other(1), (int)B, H * H, 1, st))) return rc;
-    if ((rc = run_conv(v->d_conv_out, bf.other(1), bf.other(2), nullptr, (int)B, H, H, 1, 0, st))) return rc;
+    GnRef gno{};
+    if ((rc = run_gn(v->gn_partial, v->d_norm_out, bf.X(), (int)B, H * H, 1, st, &gno))) return rc;
+    if ((rc = run_conv(v->d_conv_out, bf.X(), bf.other(2), nullptr, (int)B, H, H, 1, 0, st, &gno))) return rc;
     const int HW = H * H;
     hipLaunchKernelGGL(k_nhwc_to_nchw_clamp, dim3((HW + 255) / 256, (unsigned)B), dim3(256), 0, st, bf.other(2), images_dev,
                        c.out_ch, HW, v->d_conv_out.cout_s);
@@ -955,8 +978,9 @@ int wmar_vq_encode(wmar_vq* v, const float* images_dev, int64_t B, int64_t* code
     if ((rc = run_res(v, v->e_mid1, bf, (int)B, H, H, st))) return rc;
     if ((rc = run_attn(v, v->e_midattn, bf, (int)B, H, H, st))) return rc;
     if ((rc = run_res(v, v->e_mid2, bf, (int)B, H, H, st))) return rc;
-    if ((rc = run_gn(v->gn_partial, v->e_norm_out, bf.X(), bf.other(1), (int)B, H * H, 1, st))) return rc;
-    if ((rc = run_conv(v->e_conv_out, bf.other(1), bf.other(2), nullptr, (int)B, H, H, 1, 0, st))) return rc;
+    GnRef gne{};
+    if ((rc = run_gn(v->gn_partial, v->e_norm_out, bf.X(), (int)B, H * H, 1, st, &gne))) return rc;
+    if ((rc = run_conv(v->e_conv_out, bf.X(), bf.other(2), nullptr, (int)B, H, H, 1, 0, st, &gne))) return rc;
     if ((rc = run_conv(v->quant, bf.other(2), bf.other(3), nullptr, (int)B, H, H, 1, 0, st))) return rc;
     float* zq = bf.other(3);   // [B*S*S][E] (E is a multiple of 8: no channel padding)
     const long long P = (long long)B * S * S;
@@ -1056,16 +1080,17 @@ void mres_load(Loader& ld, const std::string& p, int cin, int cout, ResW& r) {
 int run_mres(wmar_mvq* v, const ResW& r, Bufs& bf, int B, int H, int W, hipStream_t st) {
     int rc;
     float *X = bf.X(), *A = bf.other(1), *T = bf.other(2), *C = bf.other(3);
-    if ((rc = run_gn(v->gn_partial, r.n1, X, A, B, H * W, 1, st))) return rc;
-    if ((rc = run_conv(r.c1, A, T, nullptr, B, H, W, 1, 0, st))) return rc;
-    if ((rc = run_gn(v->gn_partial, r.n2, T, A, B, H * W, 1, st))) return rc;
+    GnRef gn{};
+    if ((rc = run_gn(v->gn_partial, r.n1, X, B, H * W, 1, st, &gn))) return rc;
+    if ((rc = run_conv(r.c1, X, T, nullptr, B, H, W, 1, 0, st, &gn))) return rc;
+    if ((rc = run_gn(v->gn_partial, r.n2, T, B, H * W, 1, st, &gn))) return rc;
     if (r.has_nin) {
-        if ((rc = run_conv(r.c2, A, T, nullptr, B, H, W, 1, 0, st))) return rc;
-        if ((rc = run_conv(r.nin, T, C, T, B, H, W, 1, 0, st))) return rc;      // nin(h) + h
+        if ((rc = run_conv(r.c2, T, A, nullptr, B, H, W, 1, 0, st, &gn))) return rc;
+        if ((rc = run_conv(r.nin, A, C, A, B, H, W, 1, 0, st))) return rc;      // nin(h) + h
         bf.advance(3);
     } else {
-        if ((rc = run_conv(r.c2, A, T, X, B, H, W, 1, 0, st))) return rc;        // h + x
-        bf.advance(2);
+        if ((rc = run_conv(r.c2, T, A, X, B, H, W, 1, 0, st, &gn))) return rc;   // h + x
+        bf.advance(1);
     }
     return WMAR_OK;
 }
@@ -1154,7 +1179,7 @@ int wmar_mvq_create(const wmar_mvq_config* cfg, const char* const* names, const 
         }
     }
     for (int i = 0; i < 4; ++i) TRY(arena.alloc(&v->buf[i], maxel * v->Bmax));
-    TRY(arena.alloc(&v->gn_partial, (size_t)v->Bmax * GN_CHUNKS_MAX * 32 * 2));
+    TRY(arena.alloc(&v->gn_partial, (size_t)GN_MR_DOUBLES + (size_t)v->Bmax * GN_CHUNKS_MAX * 32 * 2));
     TRY(arena.alloc(&v->znorm, (size_t)v->Bmax * S * S));
     if (rc == WMAR_OK && hipStreamSynchronize(st) != hipSuccess) { set_error("mvq_create: sync failed"); rc = WMAR_EHIP; }
 #undef TRY
@@ -1192,8 +1217,9 @@ int wmar_mvq_decode(wmar_mvq* v, const int64_t* codes_dev, int64_t B, float* ima
             H *= 2;
         }
     }
-    if ((rc = run_gn(v->gn_partial, v->d_norm_out, bf.X(), bf.other(1), (int)B, H * H, 1, st))) return rc;
-    if ((rc = run_conv(v->d_conv_out, bf.other(1), bf.other(2), nullptr, (int)B, H, H, 1, 0, st))) return rc;
+    GnRef gno{};
+    if ((rc = run_gn(v->gn_partial, v->d_norm_out, bf.X(), (int)B, H * H, 1, st, &gno))) return rc;
+    if ((rc = run_conv(v->d_conv_out, bf.X(), bf.other(2), nullptr, (int)B, H, H, 1, 0, st, &gno))) return rc;
     const int HW = H * H;
     hipLaunchKernelGGL(k_nhwc_to_nchw_01, dim3((HW + 255) / 256, (unsigned)B), dim3(256), 0, st, bf.other(2), images_dev,
                        c.num_channels, HW, v->d_conv_out.cout_s);
@@ -1230,8 +1256,9 @@ int wmar_mvq_encode(wmar_mvq* v, const float* images_dev, int64_t B, int64_t* co
     }
     for (auto& r : v->e_mid)
         if ((rc = run_mres(v, r, bf, (int)B, H, H, st))) return rc;
-    if ((rc = run_gn(v->gn_partial, v->e_norm_out, bf.X(), bf.other(1), (int)B, H * H, 1, st))) return rc;
-    if ((rc = run_conv(v->e_conv_out, bf.other(1), bf.other(2), nullptr, (int)B, H, H, 1, 0, st))) return rc;
+    GnRef gne{};
+    if ((rc = run_gn(v->gn_partial, v->e_norm_out, bf.X(), (int)B, H * H, 1, st, &gne))) return rc;
+    if ((rc = run_conv(v->e_conv_out, bf.X(), bf.other(2), nullptr, (int)B, H, H, 1, 0, st, &gne))) return rc;
     float* zq = bf.other(2);
     const long long P = (long long)B * S * S;
     if (prequant_dev) WMAR_HIP_CHECK(hipMemcpyAsync(prequant_dev, zq, (size_t)P * z * 4, hipMemcpyDeviceToDevice, st));
