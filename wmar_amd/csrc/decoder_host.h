@@ -41,7 +41,7 @@ int copy_vec(Engine* g, float** dst, const float* src, size_t n, hipStream_t st)
 
 template <int MTW, int NW, int EPI, bool LN, int ABL = 0, int U = GEMM_STAGE, bool ROT = true>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
-    const int grid = a.NT * (a.MT / MTW) * a.S;
+    const int grid = a.NT * (a.MT / MTW) * a.S + a.n_hi;
     const size_t lds = (size_t)NW * MTW * 16 * 64 * sizeof(float);
     hipLaunchKernelGGL((k_gemm<MTW, NW, EPI, LN, ABL, U, ROT>), dim3((unsigned)grid), dim3(NW * 64), lds, st, a);
     return launch_status("k_gemm");

@@ -69,6 +69,7 @@ struct ResidArgs {
     long long gate_stride;
     const float* gate_u;       // nullable: rows >= gate_split share row *pos_dev of this [T][gate_stride] table
     int gate_split;
+    int n_hi;                  // > 0: slab S-1 exists only for column tiles < n_hi (non-uniform split of the producing GEMM)
     double* stats;             // [n_chunks][Mpad][2]
     int KB, MT, n_chunks;
     // embed
@@ -131,8 +132,10 @@ __global__ __launch_bounds__(256) void k_resid_stats(ResidArgs a) {
             r = make_float4(v[i].x + bb[i].x, v[i].y + bb[i].y, v[i].z + bb[i].z, v[i].w + bb[i].w);
         } else {
             float4 acc = sl[i][0];
+            const bool short_tile = a.n_hi > 0 && (kbs[i] >> 2) >= a.n_hi;     // this column tile has one slab fewer
 #pragma unroll
             for (int sidx = 1; sidx < S; ++sidx) {
+                if (sidx == S - 1 && short_tile) continue;
                 acc.x += sl[i][sidx].x; acc.y += sl[i][sidx].y; acc.z += sl[i][sidx].z; acc.w += sl[i][sidx].w;
             }
             float4 gg = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -207,6 +210,7 @@ struct GemmArgs {
     const float* bias;         // [N] or null
     const float* c1;           // [N] row sums of the gamma-folded weights (LN epilogue), or null
     int KB, NT, MT, S;
+    int n_hi;                  // the first n_hi column tiles are split S+1 ways, the rest S ways (fills the 256 CUs evenly; 0: uniform)
     // fused LayerNorm on the B operand
     const double* stats; int n_chunks; int K;
     // epilogues
@@ -230,15 +234,29 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int MG = a.MT / MTW;
     int bid = blockIdx.x;
-    const int nt = bid % a.NT; bid /= a.NT;
-    const int mg = bid % MG;
-    const int s = bid / MG;
+    int nt, mg, s, S_t = a.S;
+    if (bid < a.NT * MG * a.S) {
+        nt = bid % a.NT; bid /= a.NT;
+        mg = bid % MG;
+        s = bid / MG;
+        if (nt < a.n_hi) S_t = a.S + 1;
+    } else {                                   // the extra K slice of the first n_hi tiles (host: only with MG == 1)
+        nt = bid - a.NT * MG * a.S; mg = 0; s = a.S; S_t = a.S + 1;
+    }
     const int mt0 = mg * MTW;
-    const int slices = a.S * NW;
+    const int slices = S_t * NW;
     const int sl = s * NW + w;
     // 32-bit index math (there is no integer divide instruction: 64-bit division is ~10x dearer)
-    const int kb0 = (int)((unsigned)sl * (unsigned)a.KB / (unsigned)slices);
-    const int kb1 = (int)((unsigned)(sl + 1) * (unsigned)a.KB / (unsigned)slices);
+    int kb0 = (int)((unsigned)sl * (unsigned)a.KB / (unsigned)slices);
+    int kb1 = (int)((unsigned)(sl + 1) * (unsigned)a.KB / (unsigned)slices);
+    if (a.n_hi > 0 && a.KB % (NW * 2 * U) == 0) {
+        // non-uniform split: workgroup boundaries on whole pipeline rounds (NW waves x 2U k-blocks), so that no wave is left
+        // with an unpipelined tail -- e.g. 24 rounds over 5 workgroups = 4,5,5,5,5
+        const unsigned units = (unsigned)a.KB / (NW * 2 * U);
+        const int u0 = (int)((unsigned)s * units / (unsigned)S_t), u1 = (int)((unsigned)(s + 1) * units / (unsigned)S_t);
+        kb0 = (u0 * NW + w * (u1 - u0)) * 2 * U;
+        kb1 = kb0 + (u1 - u0) * 2 * U;
+    }
     const int half = lane >> 5;
 #ifdef WMAR_GEMM_TRACE
     unsigned long long tr0 = __builtin_amdgcn_s_memtime(), tr1 = 0, tr2 = 0;

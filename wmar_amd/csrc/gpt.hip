@@ -152,6 +152,7 @@ struct StepPlan {
     long long act;
     ResidArgs r{};
     int S_qkv = 1, S_proj = 1, S_fc2 = 1;
+    int fc2_hi = 0;      // FC2: the first fc2_hi column tiles take S_fc2 + 1 K slices so that exactly 256 workgroups exist
 
     StepPlan(wmar_gpt* g_, int64_t B_, const StepIO& io_, hipStream_t st_) : g(g_), B(B_), io(io_), st(st_) {
         MT = mt_for(B); D = g->D; KBD = D / 8; KBF = 4 * D / 8; nch = stat_chunks(KBD);
@@ -164,6 +165,13 @@ struct StepPlan {
         S_qkv = g->force_s[0] > 0 ? (g->force_s[0] > QKV_SLABS_MAX ? QKV_SLABS_MAX : g->force_s[0]) : 1;
         S_proj = g->force_s[1] > 0 ? g->force_s[1] : split_for(D / 32, KBD);
         S_fc2 = g->force_s[2] > 0 ? g->force_s[2] : ((MT % 2 == 0 && KBF >= 128) ? 4 : split_for(D / 32, KBF));
+        // one row-tile group (M = 64): split the tiles S / S+1 ways so that the grid is exactly one workgroup per CU
+        // (48 tiles x 4 slices = 192 workgroups leave a quarter of the CUs idle; 16 x 6 + 32 x 5 = 256)
+        if (g->force_s[2] <= 0 && MT == 2 && KBF >= 256) {
+            const int NTd = D / 32;
+            const int Slo = 256 / NTd;
+            if (Slo >= 2 && Slo < MAX_SLABS && NTd * Slo <= 256) { S_fc2 = Slo; fc2_hi = 256 - NTd * Slo; if (fc2_hi >= NTd) fc2_hi = 0; }
+        }
     }
     int split_for(int NT, int KB) const { return pick_split(MT % 2 == 0 ? NT * (MT / 2) : NT * MT, KB, 4); }
     GemmArgs base() const {
@@ -179,8 +187,8 @@ struct StepPlan {
         return launch_status("k_resid_stats<embed>");
     }
     // x += bias + sum of the S partial slabs; LN statistics of the new rows
-    int resid(const float* bias, int S) {
-        r.S = S; r.bias = bias;
+    int resid(const float* bias, int S, int n_hi = 0) {
+        r.S = S + (n_hi > 0 ? 1 : 0); r.bias = bias; r.n_hi = n_hi;
         g->span_begin(WMAR_T_RESID, st);
         int rc = launch_resid(r, nch * MT, st);
         g->span_end(st);
@@ -250,7 +258,7 @@ struct StepPlan {
     int fc2(int l) {
         GemmArgs q = base();
         q.Wp = g->layers[l].wfc2; q.Xp = g->hbuf; q.KB = KBF; q.NT = D / 32;
-        q.out_packed = g->slabs; q.slab_stride = act;
+        q.out_packed = g->slabs; q.slab_stride = act; q.n_hi = fc2_hi;
         int S = 1;
         g->span_begin(WMAR_T_FC2, st);
         int rc = gemm_split(q, &S, st, S_fc2);
@@ -274,7 +282,7 @@ int enqueue_step(wmar_gpt* g, int64_t B, const StepIO& io, hipStream_t st) {
     int rc;
     if ((rc = p.embed())) return rc;
     for (int l = 0; l < g->L; ++l) {
-        if (l > 0 && (rc = p.resid(g->layers[l - 1].bfc2, p.S_fc2))) return rc;
+        if (l > 0 && (rc = p.resid(g->layers[l - 1].bfc2, p.S_fc2, p.fc2_hi))) return rc;
         if ((rc = p.qkv(l))) return rc;
         if ((rc = p.attn(l))) return rc;
         if ((rc = p.proj(l))) return rc;
@@ -282,7 +290,7 @@ int enqueue_step(wmar_gpt* g, int64_t B, const StepIO& io, hipStream_t st) {
         if ((rc = p.fc1(l))) return rc;
         if ((rc = p.fc2(l))) return rc;
     }
-    if ((rc = p.resid(g->layers[g->L - 1].bfc2, p.S_fc2))) return rc;
+    if ((rc = p.resid(g->layers[g->L - 1].bfc2, p.S_fc2, p.fc2_hi))) return rc;
     return p.head();
 }
 
