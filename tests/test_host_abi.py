@@ -32,6 +32,30 @@ def test_ctypes_structs_match_header_layout():
     assert C.sizeof(_lib.VqConfig) == 4 * (9 + 8 + 1 + 8 + 1)
 
 
+def test_ctypes_structs_match_the_compiled_header(tmp_path):
+    """sizeof / offsetof of every ABI struct as gcc lays out include/wmar_hip.h == the ctypes mirrors in wmar_amd/_lib.py."""
+    import subprocess
+    from wmar_amd import _lib
+    pairs = {"wmar_key_params": _lib.KeyParams, "wmar_wm_ctx": _lib.WmCtx, "wmar_gpt_config": _lib.GptConfig,
+             "wmar_sample_params": _lib.SampleParams, "wmar_rar_config": _lib.RarConfig, "wmar_vq_config": _lib.VqConfig,
+             "wmar_mvq_config": _lib.MvqConfig, "wmar_cham_config": _lib.ChamConfig, "wmar_cham_sample_params": _lib.ChamSampleParams}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "wmar_hip.h"', 'int main(void) {']
+    for cname, ct in pairs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['return 0;', '}']
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, ct in pairs.items():
+        assert int(got[cname]) == C.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, f"{cname}.{fname}"
+
+
 def _wm(cfg, device="cpu", **kw):
     from wmar_amd.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
     alive = load_ids(cfg["alive"])
