@@ -217,6 +217,27 @@ def chameleon_vectors(args):
         out[f"cham_{name}_tok"] = tok[:B].numpy().astype(np.int64)
         out[f"cham_{name}_q"] = q.numpy()
         out[f"cham_{name}_params"] = np.array([h, delta, temp, top_p], dtype=np.float64)
+    # ---- the image tokenizer side: Chameleon's own VQGAN (deps/chameleon/inference/vqgan.py) on a reduced config with the
+    # released model's topology (no attention in the down/up path, one in the middle).  image_tokenizer.py itself does not
+    # import under this Python (it annotates with the PIL.Image MODULE inside typing.Union).
+    from deps.chameleon.inference.vqgan import VQModel
+    from wmar_amd.utils import synth
+    vcfg = synth.VQConfig(ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(), resolution=32, z_channels=32, embed_dim=32,
+                          n_embed=256)
+    vsd = synth.synth_vq_state(vcfg, seed=5)
+    vq = VQModel(ddconfig=dict(double_z=False, z_channels=32, resolution=32, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 2],
+                               num_res_blocks=1, attn_resolutions=[], dropout=0.0), n_embed=256, embed_dim=32).eval()
+    vq.load_state_dict(vsd, strict=True)
+    codes = torch.randint(0, 256, (2, 64), generator=g)
+    with torch.no_grad():
+        zq = vq.quantize.get_codebook_entry(codes.view(-1), (2, 8, 8, 32))
+        imgs = vq.decode(zq)
+        h = vq.quant_conv(vq.encoder(imgs))
+        _, _, (_, _, idx) = vq.encode(imgs)
+    out["chvq_codes"] = codes.numpy()
+    out["chvq_images"] = imgs.numpy()
+    out["chvq_prequant"] = h.permute(0, 2, 3, 1).reshape(-1, 32).numpy()
+    out["chvq_codes_roundtrip"] = idx.view(2, 64).numpy().astype(np.int64)
     np.savez_compressed(os.path.join(HERE, "chameleon_vectors.npz"), **out)
     print("wrote chameleon_vectors.npz", os.path.getsize(os.path.join(HERE, "chameleon_vectors.npz")), "bytes")
 

@@ -159,3 +159,16 @@ def test_generate_image_loop(graph):
     assert c2.shape == codes.shape and set(c2.flatten().tolist()) <= set(m.vocab.image_tokens)
     pv = wm.detect(codes)
     assert float(pv.median()) < 5e-2      # 64 tokens only: the watermark is visible, not overwhelming
+
+
+def test_chameleon_vqgan_reference_vectors(cv):
+    """Chameleon's own VQGAN (deps/chameleon/inference/vqgan.py, run by make_golden.py) == the VQGAN engine on the same weights."""
+    from wmar_amd.models.engine import VQGANEngine
+    vcfg = synth.VQConfig(ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(), resolution=32, z_channels=32, embed_dim=32,
+                          n_embed=256)
+    e = VQGANEngine(vcfg, synth.synth_vq_state(vcfg, seed=5), max_batch=2)
+    img = e.decode(torch.from_numpy(cv["chvq_codes"]).cuda())
+    np.testing.assert_allclose(img.cpu().numpy(), np.clip(cv["chvq_images"], -1, 1), rtol=0, atol=2e-4)
+    codes, pre = e.encode(torch.from_numpy(cv["chvq_images"]).cuda(), return_prequant=True)
+    np.testing.assert_allclose(pre.cpu().numpy(), cv["chvq_prequant"], rtol=0, atol=3e-4)
+    assert (codes.cpu().numpy() == cv["chvq_codes_roundtrip"]).mean() >= 0.99
