@@ -8,7 +8,12 @@
  *     (NULL = the default stream).  Tensors stay owned by the caller.
  *   - every function returns 0 on success or a negative WMAR_E* code;
  *     wmar_last_error() returns a human-readable message for the calling thread.
- *   - nothing here allocates after the corresponding *_create call.
+ *   - engines allocate in *_create; afterwards only small per-call scratch is allocated (prompt tables of
+ *     wmar_cham_generate_image, the one-off unconditional adaLN table of wmar_rar_generate, a status word of
+ *     wmar_gumbel_score).
+ *   - an engine handle (wmar_gpt / wmar_rar / wmar_cham / wmar_vq / wmar_mvq) is NOT thread-safe: it owns
+ *     its workspaces, KV cache and captured graphs; use it from one thread and one stream at a time
+ *     (the reference is single-threaded per model too).
  *
  * Each entry point cites the reference interface (facebookresearch/wmar) it replaces.
  */

@@ -377,7 +377,11 @@ int wmar_cham_generate_image(wmar_cham* g, const wmar_wm_ctx* wm, const int64_t*
     long long* tab_tok = nullptr;
     int* tab_pos = nullptr;
     WMAR_HIP_CHECK(hipMalloc(&tab_tok, tt.size() * 8));
-    WMAR_HIP_CHECK(hipMalloc(&tab_pos, tp.size() * 4));
+    if (hipMalloc(&tab_pos, tp.size() * 4) != hipSuccess) {
+        (void)hipFree(tab_tok);
+        set_error("cham_generate_image: out of device memory for the prompt tables");
+        return WMAR_ENOMEM;
+    }
     int rc = WMAR_OK;
     hipError_t e = hipMemcpyAsync(tab_tok, tt.data(), tt.size() * 8, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(tab_pos, tp.data(), tp.size() * 4, hipMemcpyHostToDevice, st);
