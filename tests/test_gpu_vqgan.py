@@ -76,3 +76,25 @@ def test_mid_config_vs_oracle():
     np.testing.assert_allclose(pre.cpu().numpy(), ref_z.numpy(), rtol=0, atol=5e-4)
     ref_codes = M.quantize_argmin(sd["quantize.embedding.weight"], ref_z).view(3, -1)
     assert (got_codes.cpu() == ref_codes).float().mean().item() >= 0.99
+
+
+def test_wide_config_fused_groupnorm_paths_vs_oracle():
+    """ch = 128 with multipliers (1, 2, 4): 128 / 256 / 512 channels = GroupNorm groups of 4 / 8 / 16 channels -- the configurations
+    whose statistics come from the producing conv's epilogue (per-tile partial sums) and whose normalisation + swish is applied by
+    the consuming conv's patch loader.  Small test configs (ch = 32) take the fallback statistics pass instead."""
+    from wmar_amd.models.engine import VQGANEngine
+    cfg = synth.VQConfig(ch=128, ch_mult=(1, 2, 4), num_res_blocks=1, attn_resolutions=(8,), resolution=32, z_channels=64, embed_dim=32,
+                         n_embed=512)
+    sd = synth.synth_vq_state(cfg, seed=23)
+    eng = VQGANEngine(cfg, sd, max_batch=3)
+    rs = np.random.RandomState(4)
+    codes = torch.from_numpy(rs.randint(0, cfg.n_embed, size=(3, cfg.codes_size ** 2)).astype(np.int64))
+    ref_img = M.codes_to_images(sd, cfg, codes)
+    img = eng.decode(codes.cuda())
+    np.testing.assert_allclose(img.cpu().numpy(), ref_img.numpy(), rtol=0, atol=5e-4)
+    ref_z = M.encode_prequant(sd, cfg, ref_img)
+    got_codes, pre = eng.encode(ref_img.cuda(), return_prequant=True)
+    np.testing.assert_allclose(pre.cpu().numpy(), ref_z.numpy(), rtol=0, atol=5e-4)
+    ref_codes = M.quantize_argmin(sd["quantize.embedding.weight"], ref_z).view(3, -1)
+    assert (got_codes.cpu() == ref_codes).float().mean().item() >= 0.99
+    assert torch.equal(img, eng.decode(codes.cuda()))          # deterministic

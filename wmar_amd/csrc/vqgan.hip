@@ -74,6 +74,10 @@ struct ConvArgs {
     const float2* gn_mr;      // nullable: (mean, rstd) per [image][group]
     const float* gn_g; const float* gn_b;   // per channel
     int gn_cpg, gn_swish;     // channels per group
+    // GroupNorm statistics of the OUTPUT (the next Normalize's input): per (image, 8x8 tile, group) partial (sum, sum of squares) in
+    // fp64, written by the epilogue so that no separate pass over the tensor is needed; k_gn_finalize_tiles adds the tiles in order
+    double* st_part;          // nullable: [B][tiles][32][2]
+    int st_cpg;               // output channels per group: 4, 8 or 16 (a group never straddles a 32-channel tile)
 };
 
 __device__ __forceinline__ float4 conv_gn(const ConvArgs& a, float4 v, int b, int c) {
@@ -234,6 +238,7 @@ __global__ __launch_bounds__(COT * 64) void k_conv(ConvArgs a) {
 #undef WMAR_CONV_ROUND
     if (!active) return;
     // epilogue: lane holds pixel j of each half-tile and couts ct*32 + 8g + 4*half + {0..3}
+    double gs[4] = {0.0, 0.0, 0.0, 0.0}, gss[4] = {0.0, 0.0, 0.0, 0.0};   // this lane's sums per g over its 2 pixels x 4 channels
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int oy = oy0 + p * 4 + prow, ox = ox0 + pcol;
@@ -250,6 +255,33 @@ __global__ __launch_bounds__(COT * 64) void k_conv(ConvArgs a) {
                 o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
             }
             *(float4*)(a.out + pix * a.Cout_s + co) = o;
+            if (a.st_part) {
+                gs[g] += (double)o.x + (double)o.y + (double)o.z + (double)o.w;
+                gss[g] += (double)o.x * o.x + (double)o.y * o.y + (double)o.z * o.z + (double)o.w * o.w;
+            }
+        }
+    }
+    if (a.st_part) {
+        // fold the 32 pixels of a lane half (always), the two halves (groups of >= 8 channels) and pairs of g (16 channels)
+        const int top = a.st_cpg >= 8 ? 32 : 16;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            for (int o = 1; o <= top; o <<= 1) { gs[g] += __shfl_xor(gs[g], o); gss[g] += __shfl_xor(gss[g], o); }
+        if (a.st_cpg == 16) { gs[0] += gs[1]; gss[0] += gss[1]; gs[2] += gs[3]; gss[2] += gss[3]; }
+        const long long tile = ((long long)b * a.tiles_y + ty) * a.tiles_x + tx;
+        double* dst = a.st_part + tile * 64;
+        if (a.st_cpg == 4) {              // group = ct*8 + 2g + half: lanes 0 and 32 each write four groups
+            if ((lane & 31) == 0)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { const int grp = ct * 8 + 2 * g + half; dst[grp * 2] = gs[g]; dst[grp * 2 + 1] = gss[g]; }
+        } else if (lane == 0) {
+            if (a.st_cpg == 8) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { const int grp = ct * 4 + g; dst[grp * 2] = gs[g]; dst[grp * 2 + 1] = gss[g]; }
+            } else {
+                dst[(ct * 2) * 2] = gs[0]; dst[(ct * 2) * 2 + 1] = gss[0];
+                dst[(ct * 2 + 1) * 2] = gs[2]; dst[(ct * 2 + 1) * 2 + 1] = gss[2];
+            }
         }
     }
 }
@@ -318,6 +350,25 @@ __global__ void k_gn_finalize(GnArgs a, float2* mr) {
     const double mean = ts / n;
     const double var = tss / n - mean * mean;
     mr[b * 32 + g] = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-6)));
+}
+
+// (mean, rstd) from the per-tile partial sums a conv epilogue left behind: 8 thread groups add every 8th tile in order, then
+// thread g adds the 8 partial results in order (fixed summation order, no atomics)
+__global__ __launch_bounds__(256) void k_gn_finalize_tiles(const double* part, int tiles, double count, float2* mr) {
+    __shared__ double red[8][32][2];
+    const int b = blockIdx.x, g = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const double* p = part + (long long)b * tiles * 64 + g * 2;
+    double ts = 0, tss = 0;
+    for (int t = q; t < tiles; t += 8) { ts += p[(long long)t * 64]; tss += p[(long long)t * 64 + 1]; }
+    red[q][g][0] = ts; red[q][g][1] = tss;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        ts = 0; tss = 0;
+        for (int i = 0; i < 8; ++i) { ts += red[i][g][0]; tss += red[i][g][1]; }
+        const double mean = ts / count;
+        const double var = tss / count - mean * mean;
+        mr[b * 32 + g] = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-6)));
+    }
 }
 
 // ------------------------------------------------------------------------ attention (single head)
@@ -552,6 +603,7 @@ struct wmar_vq {
     size_t buf_elems = 0;
     float *aq = nullptr, *ak = nullptr, *av = nullptr, *ao = nullptr, *asc = nullptr;
     double* gn_partial = nullptr;
+    double* gn_tiles = nullptr; long long gn_tiles_cap = 0;   // per-tile GroupNorm partial sums written by conv epilogues
     float* znorm = nullptr;
 
     template <typename T>
@@ -659,6 +711,14 @@ bool in_attn_res(const wmar_vq_config& c, int res) {
 
 static bool vq_trace() { static int v = -1; if (v < 0) { const char* e = getenv("WMAR_VQ_TRACE"); v = e ? atoi(e) : 0; } return v != 0; }
 
+// Which tensor the per-tile statistics buffer currently describes.  Set by the conv that produced the tensor, consumed by the
+// next run_gn on it; one call (decode / encode) at a time per thread.
+struct GnTrack {
+    double* part = nullptr; long long cap = 0;      // [B][tiles][32][2] doubles, capacity in doubles
+    const float* src = nullptr; int tiles = 0, C = 0;
+};
+static thread_local GnTrack g_trk;
+
 // a GroupNorm whose statistics are ready and whose normalisation is applied by the convs that consume it
 struct GnRef {
     const float2* mr; const float* g; const float* b; int C, swish;
@@ -682,6 +742,12 @@ int run_conv(const ConvW& c, const float* in, float* out, const float* res, int 
     const int PW = 7 * stride + c.ks;
     const int COT = c.CT >= 4 ? 4 : (c.CT >= 2 ? 2 : 1);
     a.dbuf = (c.cin_s % CONV_CCH == 0 && PW * PW * 8 <= 4 * COT * 64) ? 1 : 0;
+    // statistics of the output for the GroupNorm that (usually) follows: groups of 4 / 8 / 16 channels inside one 32-channel tile
+    const int cpg_out = c.cout / 32;
+    const bool stats = g_trk.part && c.cout == c.cout_s && c.cout % 32 == 0 && (cpg_out == 4 || cpg_out == 8 || cpg_out == 16) &&
+                       (long long)B * a.tiles_x * a.tiles_y * 64 <= g_trk.cap;
+    if (stats) { a.st_part = g_trk.part; a.st_cpg = cpg_out; g_trk.src = out; g_trk.tiles = a.tiles_x * a.tiles_y; g_trk.C = c.cout; }
+    else if (g_trk.src == out) g_trk.src = nullptr;      // the tensor the buffer described is being overwritten
     const size_t lds = (size_t)(a.dbuf ? 2 : 1) * PW * PW * CONV_PSTRIDE * sizeof(float);
     const int cgroups = (c.CT + COT - 1) / COT;
     const unsigned grid = (unsigned)((long long)B * cgroups * a.tiles_x * a.tiles_y);
@@ -710,10 +776,16 @@ int run_gn(double* gn_partial, const NormW& n, const float* x, int B, int HW, in
     if (nchunk < 1) nchunk = 1;
     if (nchunk > GN_CHUNKS_MAX) nchunk = GN_CHUNKS_MAX;
     a.nchunk = nchunk;
-    hipLaunchKernelGGL(k_gn_partial, dim3(nchunk, B), dim3(256), 0, st, a);
     WMAR_REQUIRE(B <= GN_MR_DOUBLES / 32, "GroupNorm: batch %d too large", B);
     float2* mr = (float2*)gn_partial;
-    hipLaunchKernelGGL(k_gn_finalize, dim3(B), dim3(32), 0, st, a, mr);
+    if (g_trk.part && g_trk.src == x && g_trk.C == n.C && g_trk.tiles * 64 == HW) {
+        // the conv that produced x already left per-tile sums behind: no pass over the tensor
+        hipLaunchKernelGGL(k_gn_finalize_tiles, dim3(B), dim3(256), 0, st, (const double*)g_trk.part, g_trk.tiles,
+                           (double)HW * (n.C / 32), mr);
+    } else {
+        hipLaunchKernelGGL(k_gn_partial, dim3(nchunk, B), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_gn_finalize, dim3(B), dim3(32), 0, st, a, mr);
+    }
     out->mr = mr; out->g = n.g; out->b = n.b; out->C = n.C; out->swish = swish;
     return launch_status("k_gn");
 }
@@ -895,6 +967,8 @@ int wmar_vq_create(const wmar_vq_config* cfg, const char* const* names, const vo
     TRY(v->alloc(&v->ao, (size_t)v->Bmax * ntok * cam));
     TRY(v->alloc(&v->asc, (size_t)v->Bmax * ntok * ntok));
     TRY(v->alloc(&v->gn_partial, (size_t)GN_MR_DOUBLES + (size_t)v->Bmax * GN_CHUNKS_MAX * 32 * 2));
+    v->gn_tiles_cap = (long long)v->Bmax * (cfg->resolution / 8) * (cfg->resolution / 8) * 64;
+    TRY(v->alloc(&v->gn_tiles, (size_t)v->gn_tiles_cap));
     TRY(v->alloc(&v->znorm, (size_t)v->Bmax * S * S));
     if (rc == WMAR_OK && hipStreamSynchronize(st) != hipSuccess) { set_error("vq_create: sync failed"); rc = WMAR_EHIP; }
 #undef TRY
@@ -914,6 +988,8 @@ int wmar_vq_decode(wmar_vq* v, const int64_t* codes_dev, int64_t B, float* image
     const int L = c.n_levels, S = v->S, E = c.embed_dim;
     int rc;
     Bufs bf{v->buf};
+    g_trk = GnTrack{};
+    g_trk.part = v->gn_tiles; g_trk.cap = v->gn_tiles_cap;
     // get_codebook_entry (quantize.py:316-331): z_q in NHWC is just the gathered rows
     const long long npix = (long long)B * S * S;
     hipLaunchKernelGGL(k_codebook_gather, dim3((unsigned)((npix * (E / 4) + 255) / 256)), dim3(256), 0, st,
@@ -957,6 +1033,8 @@ int wmar_vq_encode(wmar_vq* v, const float* images_dev, int64_t B, int64_t* code
     const int L = c.n_levels, S = v->S, E = c.embed_dim;
     int rc;
     Bufs bf{v->buf};
+    g_trk = GnTrack{};
+    g_trk.part = v->gn_tiles; g_trk.cap = v->gn_tiles_cap;
     int H = c.resolution;
     hipLaunchKernelGGL(k_nchw_to_nhwc, dim3((H * H + 255) / 256, (unsigned)B), dim3(256), 0, st, images_dev, bf.X(),
                        c.in_channels, H * H, v->e_conv_in.cin_s);
@@ -1061,6 +1139,7 @@ struct wmar_mvq {
     float* emb = nullptr; float4* emb_p = nullptr; float* enorm = nullptr;
     float* buf[4] = {nullptr, nullptr, nullptr, nullptr};
     double* gn_partial = nullptr;
+    double* gn_tiles = nullptr; long long gn_tiles_cap = 0;   // per-tile GroupNorm partial sums written by conv epilogues
     float* znorm = nullptr;
     ~wmar_mvq() { for (void* p : allocs) (void)hipFree(p); }
 };
@@ -1180,6 +1259,8 @@ int wmar_mvq_create(const wmar_mvq_config* cfg, const char* const* names, const 
     }
     for (int i = 0; i < 4; ++i) TRY(arena.alloc(&v->buf[i], maxel * v->Bmax));
     TRY(arena.alloc(&v->gn_partial, (size_t)GN_MR_DOUBLES + (size_t)v->Bmax * GN_CHUNKS_MAX * 32 * 2));
+    v->gn_tiles_cap = (long long)v->Bmax * (cfg->resolution / 8) * (cfg->resolution / 8) * 64;
+    TRY(arena.alloc(&v->gn_tiles, (size_t)v->gn_tiles_cap));
     TRY(arena.alloc(&v->znorm, (size_t)v->Bmax * S * S));
     if (rc == WMAR_OK && hipStreamSynchronize(st) != hipSuccess) { set_error("mvq_create: sync failed"); rc = WMAR_EHIP; }
 #undef TRY
@@ -1199,6 +1280,8 @@ int wmar_mvq_decode(wmar_mvq* v, const int64_t* codes_dev, int64_t B, float* ima
     const int R = c.n_levels, S = v->S, z = c.z_channels;
     int rc;
     Bufs bf{v->buf};
+    g_trk = GnTrack{};
+    g_trk.part = v->gn_tiles; g_trk.cap = v->gn_tiles_cap;
     const long long npix = (long long)B * S * S;
     hipLaunchKernelGGL(k_codebook_gather, dim3((unsigned)((npix * (z / 4) + 255) / 256)), dim3(256), 0, st,
                        (const long long*)codes_dev, v->emb, bf.X(), npix, z, c.num_embeddings);
@@ -1234,6 +1317,8 @@ int wmar_mvq_encode(wmar_mvq* v, const float* images_dev, int64_t B, int64_t* co
     const int R = c.n_levels, S = v->S, z = c.z_channels;
     int rc;
     Bufs bf{v->buf};
+    g_trk = GnTrack{};
+    g_trk.part = v->gn_tiles; g_trk.cap = v->gn_tiles_cap;
     int H = c.resolution;
     hipLaunchKernelGGL(k_nchw_to_nhwc01, dim3((H * H + 255) / 256, (unsigned)B), dim3(256), 0, st, images_dev, bf.X(),
                        c.num_channels, H * H, v->e_conv_in.cin_s);
@@ -1249,6 +1334,7 @@ int wmar_mvq_encode(wmar_mvq* v, const float* images_dev, int64_t B, int64_t* co
             int gx = (int)((total + 255) / 256);
             if (gx > 8192) gx = 8192;
             hipLaunchKernelGGL(k_avgpool2, dim3(gx, (unsigned)B), dim3(256), 0, st, bf.X(), bf.other(1), H / 2, H / 2, C);
+            if (g_trk.src == bf.other(1)) g_trk.src = nullptr;
             if ((rc = launch_status("k_avgpool2"))) return rc;
             bf.advance(1);
             H /= 2;
