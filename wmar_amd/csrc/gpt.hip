@@ -271,7 +271,21 @@ struct StepPlan {
         h.Wp = g->whead; h.Xp = g->x; h.KB = KBD; h.NT = g->V / 32;
         h.bias = g->bhead; h.c1 = g->chead; h.logits = io.logits; h.V = g->V;
         g->span_begin(WMAR_T_HEAD, st);
-        int rc = gemm_dispatch<EPI_LOGITS, true>(h, false, st);
+        // at most one workgroup per CU per launch: two workgroups on a CU share its MFMA pipes and L1 fill path, so 512 column
+        // tiles run faster as two launches of 256 than as one of 512 (measured 56 us -> see DESIGN.md section 6)
+        const int MG = (MT % 2 == 0) ? MT / 2 : MT;
+        const int per = 256 / MG > 0 ? 256 / MG : 1;
+        int rc = WMAR_OK;
+        const int NTall = h.NT;
+        for (int nt0 = 0; nt0 < NTall && rc == WMAR_OK; nt0 += per) {
+            GemmArgs p = h;
+            p.NT = NTall - nt0 < per ? NTall - nt0 : per;
+            p.Wp = h.Wp + (long long)nt0 * h.KB * 64;
+            p.bias = h.bias ? h.bias + (long long)nt0 * 32 : nullptr;
+            p.c1 = h.c1 + (long long)nt0 * 32;
+            p.logits = h.logits + (long long)nt0 * 32;
+            rc = gemm_dispatch<EPI_LOGITS, true>(p, false, st);
+        }
         g->span_end(st);
         return rc;
     }
