@@ -53,6 +53,11 @@ def get_parser():
     parser.add_argument("--syncpath", type=str)
     parser.add_argument("--seed", type=int, nargs="?", help="seed", default=42)
     parser.add_argument("--synthetic", type=str2bool, default=False, help="random-init weights instead of checkpoints")
+    parser.add_argument("--synthetic_config", type=str, default="full", choices=["full", "harness"],
+                        help="with --synthetic: 'full' = the released architecture; 'harness' = the reduced Taming model of "
+                             "tests/golden/harness_vectors.npz (what the reference's own generate.py was run on)")
+    parser.add_argument("--noise_device", type=str, default=None, choices=[None, "cpu"],
+                        help="'cpu': draw the multinomial noise from the CPU generator (reproduces a CPU run of the reference)")
     parser.add_argument("--augmentations", type=str2bool, default=True,
                         help="run the classic robustness transforms (blur, noise, jpeg, brightness, rotation, flip, crop)")
     return parser
@@ -89,7 +94,12 @@ def main():
     device = f"cuda:{local_rank}"
     seed = args.seed + 1000 * chunk_id
     if args.model == "taming":
-        if args.synthetic:
+        if args.synthetic and args.synthetic_config == "harness":
+            gcfg, vcfg = synth.GPTConfig(**synth.HARNESS_GPT), synth.VQConfig(**synth.HARNESS_VQ)
+            model = TamingARMMWrapper(None, gpt_cfg=gcfg, vq_cfg=vcfg, gpt_state=synth.synth_gpt_state(gcfg, 21, "cpu", 40.0),
+                                      vq_state=synth.synth_vq_state(vcfg, 21, "cpu"), device=device,
+                                      max_batch=min(args.batch_size, 128))
+        elif args.synthetic:
             model = TamingARMMWrapper.synthetic(synth.TAMING_GPT, synth.TAMING_VQ, seed=0, device=device,
                                                 max_batch=min(args.batch_size, 128))
         else:
@@ -104,6 +114,7 @@ def main():
             model = ChameleonARMMWrapper.synthetic(seed=seed, device=device, max_batch=min(args.batch_size, 16))
         else:
             model = ChameleonARMMWrapper(args.modelpath, seed, device=device, max_batch=min(args.batch_size, 16))
+    model.noise_device = args.noise_device
     if args.encoder_ft_ckpt is not None and args.encoder_ft_ckpt != "none":
         assert args.model == "taming", "delta checkpoints are wired for the Taming VQGAN only"
         update_weights(model, "encoder", args.encoder_ft_ckpt)
@@ -133,16 +144,7 @@ def main():
                                        SplitStrategy(args.wm_split_strategy), args.wm_context_size, args.wm_delta,
                                        args.wm_gamma, model.device)
         if world > 1:  # build the key once, broadcast it over RCCL
-            if dist.get_rank() == 0:
-                table = watermarker.key_table()
-                shape = torch.tensor(list(table.shape), device=device)
-            else:
-                shape = torch.zeros(2, dtype=torch.int64, device=device)
-            dist.broadcast(shape, 0)
-            if dist.get_rank() != 0:
-                table = torch.empty(tuple(shape.tolist()), dtype=torch.int32, device=device)
-            dist.broadcast(table, 0)
-            watermarker.set_key_table(table)
+            harness.broadcast_key_table(watermarker, device)
     model.set_watermarker(watermarker)
 
     # evaluation transforms: the classic ones run batched on the GPU; neural codecs and DiffPure are outside this build
@@ -160,15 +162,15 @@ def main():
     recs = harness.generate(args.outdir, model, all_inputs, watermarker, eval_params, gen_params, chunk_id=chunk_id,
                             num_chunks=num_chunks)
     if world > 1:
-        gathered = [None] * world if dist.get_rank() == 0 else None
-        dist.gather_object(recs, gathered, dst=0)
-        if dist.get_rank() == 0:
-            recs = [r for part in gathered for r in part]
+        for r in recs:
+            if isinstance(r["conditioning"], tuple):
+                r["conditioning"] = r["conditioning"][0]
+        recs = harness.gather_records(recs, eval_params, device)      # tensors over RCCL: codes, p-values, l0, psnr
         dist.barrier()
         dist.destroy_process_group()
     if chunk_id == 0 or world == 1:
         with open(os.path.join(args.outdir, "results.json"), "w") as f:
-            json.dump(recs, f)
+            json.dump([{k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in r.items()} for r in recs], f)
         from wmar_amd.utils.analyzer import summarize
         with open(os.path.join(args.outdir, "summary.json"), "w") as f:      # TPR@1%FPR, mean l0 / PSNR per (method, transform, param)
             json.dump(summarize(recs), f, indent=1)

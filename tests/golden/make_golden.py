@@ -19,6 +19,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
 
 
 def _stubs(d):
@@ -280,20 +281,325 @@ def gumbel_vectors(args):
     print("wrote gumbel_vectors.npz", os.path.getsize(os.path.join(HERE, "gumbel_vectors.npz")), "bytes")
 
 
+PROD_POS = [0, 1, 31, 32, 33, 111, 112, 113, 207, 208, 209, 255]
+PROD_RAR_STEPS = [0, 1, 2, 14, 15, 16, 17, 31, 32, 33, 62, 63, 64, 110, 111, 112, 113, 206, 207, 208, 209, 254, 255]
+
+
+def prod_vectors(args):
+    """Production-width fixtures: the kernel variants the benchmark runs -- 1536-wide GEMMs with the
+    non-uniform split-K FC2 and the two-launch vocabulary head, 1 / 2 / 4 attention waves per (sequence, head), the multi-chunk
+    KV loop, 6 statistics chunks -- only exist at n_embd >= 512 and cache lengths > 112 / > 208.  The reference GPT
+    (mingpt.py:125-214) is run here at 2 layers x 1536 x 24 heads, block 256, 64 rows, teacher-forced through all 256 positions;
+    RAR (rar.py:319-459) at 2 layers x 1280 x 16 heads (head_dim 80), 64 conditions under guidance = 128 rows, 256 steps."""
+    import torch
+    from deps.taming.modules.transformer.mingpt import GPT, sample_with_past
+    from deps.rar.modeling.rar import RAR
+    from wmar.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
+    from wmar_amd.utils import synth
+
+    torch.set_num_threads(8)
+    out = {}
+
+    def ids_file(name):
+        ids = []
+        for line in open(os.path.join(args.ref, "assets", name)):
+            ids.extend(int(t) for t in line.split(","))
+        return ids
+
+    def vq_dict(alive, vocab):
+        dead = list(set(range(vocab)) - set(alive))
+        return {"alive_ids": torch.tensor(alive, dtype=torch.long), "dead_ids": torch.tensor(dead, dtype=torch.long),
+                "embedding": torch.zeros(vocab, 4)}
+
+    # ------------------------------------------------------------------ Taming GPT, production width
+    cfg = synth.GPTConfig(vocab_size=16384, block_size=256, n_layer=2, n_head=24, n_embd=1536)
+    sd = synth.synth_gpt_state(cfg, seed=9, logit_scale=10.0, with_mask=True)
+    gpt = GPT(vocab_size=cfg.vocab_size, block_size=cfg.block_size, n_layer=cfg.n_layer, n_head=cfg.n_head, n_embd=cfg.n_embd)
+    gpt.load_state_dict(sd, strict=True)
+    gpt.eval()
+    B = 64
+    rs = np.random.RandomState(20260929)
+    seq = rs.randint(0, 16384, size=(B, 256)).astype(np.int64)
+    seq[:, 0] = [(i * 37) % 1000 for i in range(B)]
+    seq_t = torch.from_numpy(seq)
+    past = None
+    lgs, amax = [], []
+    with torch.no_grad():
+        for t in range(256):
+            lg, _, present = gpt.forward_with_past(seq_t[:, t:t + 1], past=past, past_length=t)
+            past = [present] if past is None else past + [present]
+            lg = lg[:, -1, :]
+            amax.append(lg.argmax(-1).numpy())
+            if t in PROD_POS:
+                lgs.append(lg[:, ::64].numpy().copy())
+    out["gpt_seq"] = seq.astype(np.int16)                      # [64,256] teacher-forcing tokens
+    out["gpt_pos"] = np.array(PROD_POS, dtype=np.int32)
+    out["gpt_logits"] = np.stack(lgs)                           # [12,64,256]: every 64th logit
+    out["gpt_argmax"] = np.stack(amax).astype(np.int16)         # [256,64]
+    print("gpt teacher-forced done; |logit| max %.2f std %.2f" % (np.abs(out["gpt_logits"]).max(), out["gpt_logits"].std()), flush=True)
+
+    wm = GentimeWatermark(vq_dict(ids_file("vqgan_alive_ids.txt"), 16384), 16384, SeedStrategy.LINEAR,
+                          SplitStrategy.RANDOM_STRATIFIED, 1, 2.0, 0.25)
+    cond = torch.tensor([[7], [980], [1], [340]], dtype=torch.long)
+    torch.manual_seed(11)
+    toks = sample_with_past(cond, gpt, steps=256, temperature=1.0, sample_logits=True, top_k=250, top_p=0.92,
+                            logit_processor=wm.spawn_logit_processor())
+    out["loop_cond"] = cond.numpy()
+    out["loop_tokens"] = toks.numpy().astype(np.int16)          # q: torch.manual_seed(11), 256 draws of [4,16384] Exp(1)
+    out["loop_pvals"] = wm.detect(toks).numpy()
+    print("gpt loop done", flush=True)
+
+    # ------------------------------------------------------------------ RAR, production width (head_dim 80)
+    class AD(dict):
+        def __getattr__(self, k):
+            v = self[k]
+            return AD(v) if isinstance(v, dict) else v
+
+        def get(self, k, d=None):
+            return dict.get(self, k, d)
+
+    rcfg = synth.RARConfig(hidden_size=1280, num_hidden_layers=2, num_attention_heads=16, intermediate_size=5120,
+                           image_seq_len=256, codebook_size=1024, condition_num_classes=1000)
+    cfgd = AD(model=dict(vq_model=dict(codebook_size=1024),
+                         generator=dict(hidden_size=1280, num_hidden_layers=2, num_attention_heads=16, intermediate_size=5120,
+                                        image_seq_len=256, condition_num_classes=1000, dropout=0.0, attn_drop=0.0)))
+    rsd = synth.synth_rar_state(rcfg, seed=12, logit_scale=8.0)
+    gen = RAR(cfgd).eval()
+    gen.load_state_dict(rsd, strict=True)
+    gen.set_random_ratio(0)
+    wmr = GentimeWatermark(vq_dict(ids_file("rar_all_ids.txt"), 1024), 1024, SeedStrategy.LINEAR,
+                           SplitStrategy.RANDOM_STRATIFIED, 1, 2.0, 0.25)
+    rec = {}
+    orig = gen.forward_fn
+    state = {"n": 0}
+
+    def spy(ids, condition, **kw):
+        r = orig(ids, condition, **kw)
+        if state["n"] in PROD_RAR_STEPS:
+            rec[state["n"]] = r[:, -1, ::8].detach().clone().numpy()
+        state["n"] += 1
+        return r
+
+    gen.forward_fn = spy
+    condr = torch.tensor([[(i * 13) % 1000] for i in range(64)], dtype=torch.long)
+    torch.manual_seed(31)
+    toks = gen.generate(condition=condr, guidance_scale=4.0, guidance_scale_pow=0.0, randomize_temperature=1.0,
+                        logit_processor=wmr.spawn_logit_processor())
+    out["rar_cond"] = condr.view(-1).numpy().astype(np.int16)
+    out["rar_tokens"] = toks.numpy().astype(np.int16)          # [64,256]: teacher-forcing tokens for the logits below
+    out["rar_steps"] = np.array(PROD_RAR_STEPS, dtype=np.int32)
+    out["rar_logits"] = np.stack([rec[s] for s in PROD_RAR_STEPS])   # [23,128,128]: cond rows then uncond rows, every 8th logit
+    print("rar B=64 done; |logit| max %.2f std %.2f" % (np.abs(out["rar_logits"]).max(), out["rar_logits"].std()), flush=True)
+    state["n"] = -10 ** 9
+    cond4 = torch.tensor([[3], [977], [0], [512]], dtype=torch.long)
+    torch.manual_seed(21)
+    toks4 = gen.generate(condition=cond4, guidance_scale=4.0, guidance_scale_pow=0.0, randomize_temperature=1.0,
+                         logit_processor=wmr.spawn_logit_processor())
+    out["rar_loop_cond"] = cond4.view(-1).numpy()
+    out["rar_loop_tokens"] = toks4.numpy().astype(np.int16)    # q: manual_seed(21), rand(4,1), 256 draws of [4,1024] Exp(1)
+    out["rar_loop_pvals"] = wmr.detect(toks4).numpy()
+    gen.forward_fn = orig
+    np.savez_compressed(os.path.join(HERE, "prod_vectors.npz"), **out)
+    print("wrote prod_vectors.npz", os.path.getsize(os.path.join(HERE, "prod_vectors.npz")), "bytes")
+
+
+# ------------------------------------------------------------------ bulk sampler decisions (VERDICT r1, item 2)
+from bulk_inputs import BULK_CHUNKS, BULK_ROWS, BULK_V, bulk_noise, bulk_rows  # noqa: E402  (same directory)
+
+
+def sampler_bulk_vectors(args):
+    """24 576 decisions of the reference's sampling chain (mingpt.py:348-363): GentimeWatermark._process_logits -> /T ->
+    HF TopKLogitsWarper -> TopPLogitsWarper -> softmax -> torch.multinomial, V = 16384, logit scales 1 / 10 / 40, plain /
+    tie-heavy / bf16-valued rows.  Only the tokens are stored; inputs are regenerated from the chunk index."""
+    import torch
+    import torch.nn.functional as F
+    from transformers import TopKLogitsWarper, TopPLogitsWarper
+    from wmar.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
+
+    torch.set_num_threads(8)
+    ids = []
+    for line in open(os.path.join(args.ref, "assets", "vqgan_alive_ids.txt")):
+        ids.extend(int(t) for t in line.split(","))
+    dead = list(set(range(BULK_V)) - set(ids))
+    vq = {"alive_ids": torch.tensor(ids), "dead_ids": torch.tensor(dead), "embedding": torch.zeros(BULK_V, 4)}
+    wm = GentimeWatermark(vq, BULK_V, SeedStrategy.LINEAR, SplitStrategy.RANDOM_STRATIFIED, 1, 2.0, 0.25)
+    proc = wm.spawn_logit_processor()
+    toks = np.zeros((BULK_CHUNKS, BULK_ROWS), dtype=np.int16)
+    for c in range(BULK_CHUNKS):
+        ctx, lg, top_k, top_p, T, use_wm = bulk_rows(c)
+        logits = lg.clone()
+        if use_wm:
+            logits = proc(past_ids=ctx, logits=logits)
+        logits = logits / T
+        if top_k is not None:
+            logits = TopKLogitsWarper(top_k=top_k)(input_ids=ctx, scores=logits)
+        if top_p is not None:
+            logits = TopPLogitsWarper(top_p=top_p)(input_ids=ctx, scores=logits)
+        probs = F.softmax(logits, dim=-1)
+        torch.manual_seed(88000 + c)
+        toks[c] = torch.multinomial(probs, num_samples=1).view(-1).numpy()
+        print("chunk", c, flush=True)
+    np.savez_compressed(os.path.join(HERE, "sampler_bulk.npz"), tokens=toks)
+    print("wrote sampler_bulk.npz", os.path.getsize(os.path.join(HERE, "sampler_bulk.npz")), "bytes")
+
+
+# ------------------------------------------------------------------ harness / metrics / delta checkpoints (A13, A14, f1)
+# the reduced model: wmar_amd.utils.synth.HARNESS_GPT / HARNESS_VQ (GPT 2L x 128d over the 16384-code vocabulary, VQGAN at 32 px)
+HARNESS_INPUTS = [c for c in (1, 9) for _ in range(3)]          # 2 classes x 3 samples, batch 4 -> batches of 4 and 2
+HARNESS_GEN = {"batch_size": 4, "temperature": 1.0, "top_k": 250, "top_p": 0.92}
+HARNESS_EVAL = {"metric_names": ["pvalue", "l0", "psnr"], "augmentations": [], "max_roundtrips": 1, "orig_only": False}
+
+
+def _placeholder_modules():
+    """generate.py imports, at module level, wrappers and managers whose dependencies are absent here (diffusers, xformers,
+    real torchvision).  None of them is on the Taming path under test (generate / fill_batch_log /
+    compute_metrics_and_save_from_batch_log / compute_metric / chw_to_pillow / update_weights / TamingARMMWrapper); they are
+    replaced by empty placeholder modules that only carry the imported names."""
+    import types
+    for name, attrs in [("wmar.augmentations.augmentation_manager", ["AugmentationManager"]),
+                        ("wmar.models.chameleon_wrapper", ["ChameleonARMMWrapper"]),
+                        ("wmar.models.rar_wrapper", ["RarARMMWrapper"]),
+                        ("wmar.watermarking.synchronization", ["SyncManager"]),
+                        ("omegaconf", ["OmegaConf"]),
+                        ("deps.rar.utils.train_utils", ["create_pretrained_tokenizer"])]:
+        m = types.ModuleType(name)
+        for a in attrs:
+            setattr(m, a, type(a, (), {}))
+        sys.modules[name] = m
+
+
+def harness_vectors(args):
+    """The reference's generate.generate (generate.py:168-232) on a reduced Taming model: class ids + seed -> codes, p-values,
+    l0, psnr, file names (SURVEY 8c); compute_metric / chw_to_pillow known answers (metrics.py:20-45, utils.py:74-80);
+    update_weights on encoder / decoder delta checkpoints (utils.py:47-66)."""
+    import random
+    import shutil
+    import torch
+    from PIL import Image
+    _placeholder_modules()
+    import generate as RG
+    from deps.taming.models.cond_transformer import Net2NetTransformer
+    from wmar.models.taming_wrapper import TamingARMMWrapper
+    from wmar.utils.metrics import compute_metric, compute_psnr
+    from wmar.utils.utils import chw_to_pillow, update_weights
+    from wmar.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
+    from wmar_amd.utils import synth
+
+    torch.set_num_threads(8)
+    out = {}
+    gcfg = synth.GPTConfig(**synth.HARNESS_GPT)
+    vcfg = synth.VQConfig(**synth.HARNESS_VQ)
+    gs = synth.synth_gpt_state(gcfg, seed=21, logit_scale=40.0, with_mask=True)
+    vs = synth.synth_vq_state(vcfg, seed=21)
+    dd = dict(double_z=False, z_channels=vcfg.z_channels, resolution=vcfg.resolution, in_channels=3, out_ch=3, ch=vcfg.ch,
+              ch_mult=list(vcfg.ch_mult), num_res_blocks=vcfg.num_res_blocks, attn_resolutions=list(vcfg.attn_resolutions),
+              dropout=0.0)
+    net = Net2NetTransformer(
+        transformer_config={"target": "deps.taming.modules.transformer.mingpt.GPT", "params": dict(synth.HARNESS_GPT)},
+        first_stage_config={"target": "deps.taming.models.vqgan.VQModel",
+                            "params": dict(embed_dim=vcfg.embed_dim, n_embed=vcfg.n_embed, ddconfig=dd,
+                                           lossconfig={"target": "deps.taming.modules.losses.DummyLoss"})},
+        cond_stage_config={"target": "deps.taming.modules.util.Labelator", "params": {"n_classes": 1000}})
+    sd = {"transformer." + k: v for k, v in gs.items()}
+    sd.update({"first_stage_model." + k: v for k, v in vs.items()})
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith(("first_stage_model.loss", "cond_stage_model")) for k in missing), (missing, unexpected)
+    net.eval()
+
+    def wrapper():
+        w = object.__new__(TamingARMMWrapper)       # __init__ needs omegaconf + "cuda" + checkpoint files (SURVEY 8c)
+        w.model = net
+        w.init_alivecodes(os.path.join(args.ref, "assets", "vqgan_alive_ids.txt"))
+        w.codes_size, w.image_size, w.dim_z = vcfg.codes_size, vcfg.resolution, vcfg.embed_dim
+        return w
+
+    w = wrapper()
+    wm = GentimeWatermark(w.get_vq(), w.get_total_vocab_size(), SeedStrategy.LINEAR, SplitStrategy.RANDOM_STRATIFIED, 1, 2.0, 0.25,
+                          device="cpu")
+    w.set_watermarker(wm)
+    out["wm_str"] = np.array(str(wm))
+
+    def run(chunk_id, num_chunks, tag):
+        seed = 1 + 1000 * chunk_id                   # generate.py:304-308
+        random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+        d = tempfile.mkdtemp(prefix="wmar_harness_")
+        RG.generate(d, w, HARNESS_INPUTS, wm, HARNESS_EVAL, HARNESS_GEN, chunk_id=chunk_id, num_chunks=num_chunks)
+        files = sorted(os.path.relpath(os.path.join(r, f), d) for r, _, fs in os.walk(d) for f in fs)
+        out[f"{tag}_files"] = np.array(files)
+        codes, metrics, pngs = [], [], []
+        for f in files:
+            if f.endswith(".npy"):
+                codes.append(np.load(os.path.join(d, f)))
+                metrics.append(json.load(open(os.path.join(d, f[:-4] + ".json"))))
+                pngs.append(np.array(Image.open(os.path.join(d, f[:-4] + ".png"))))
+        out[f"{tag}_codes"] = np.stack(codes).astype(np.int64)              # in the order of the sorted .npy names
+        out[f"{tag}_pvalue"] = np.array([m["pvalue"] for m in metrics], dtype=np.float64)
+        out[f"{tag}_l0"] = np.array([m["l0"] for m in metrics], dtype=np.float64)
+        out[f"{tag}_psnr"] = np.array([m["psnr"] for m in metrics], dtype=np.float64)
+        out[f"{tag}_png"] = np.stack(pngs)
+        shutil.rmtree(d)
+
+    run(0, 1, "job")
+    run(0, 2, "chunk0of2")
+    run(1, 2, "chunk1of2")
+
+    # ---- A13 known answers on crafted inputs
+    rs = np.random.RandomState(5)
+    a = rs.randint(0, 16384, size=64).astype(np.int64)
+    b = a.copy()
+    b[rs.choice(64, 11, replace=False)] += 1
+    ia = (rs.rand(3, 32, 32).astype(np.float32) * 2.4 - 1.2)                  # outside [-1,1] too: the clip matters
+    ib = np.clip(ia + rs.randn(3, 32, 32).astype(np.float32) * 0.05, -1.5, 1.5)
+    ticks = (np.arange(256, dtype=np.float64) + 0.5) / 255.0 * 2.0 - 1.0      # values that land on k + 0.5 before rounding
+    ia[0, 0, :] = ticks[:32].astype(np.float32)
+    ia[0, 1, :] = ticks[100:132].astype(np.float32)
+    pa, pb = chw_to_pillow(ia), chw_to_pillow(torch.from_numpy(ib))
+    out["met_code_a"], out["met_code_b"] = a, b
+    out["met_img_a"], out["met_img_b"] = ia, ib
+    out["met_u8_a"], out["met_u8_b"] = np.array(pa), np.array(pb)
+    out["met_l0"] = np.array(compute_metric("l0", b, a, pb, pa, wm, "roundtrips", 0))
+    out["met_psnr"] = np.array(compute_metric("psnr", b, a, pb, pa, wm, "roundtrips", 0))
+    out["met_psnr_same"] = np.array(compute_psnr(pa, pa))
+    out["met_pvalue"] = np.array(compute_metric("pvalue", b, a, pb, pa, wm, "roundtrips", 0))
+    out["met_bpp"] = np.array(-1.0 if compute_metric("bpp", b, a, pb, pa, wm, "roundtrips", 0) is None else 1.0)
+
+    # ---- f1: delta checkpoints through the reference's update_weights
+    codes = torch.from_numpy(rs.randint(0, 16384, size=(2, vcfg.codes_size ** 2)).astype(np.int64))
+    img0 = w.codes_to_images(codes)
+    c0 = w.images_to_codes(img0)
+    tmpd = tempfile.mkdtemp(prefix="wmar_delta_")
+    torch.save(synth.synth_delta(vs, "decoder.", seed=1), os.path.join(tmpd, "dec_delta.pth"))
+    torch.save({"state_dict": synth.synth_delta(vs, "encoder.", seed=2)}, os.path.join(tmpd, "enc_delta.pth"))
+    update_weights(w.get_image_tokenizer().decoder, os.path.join(tmpd, "dec_delta.pth"))
+    img1 = w.codes_to_images(codes)
+    update_weights(w.get_image_tokenizer().encoder, os.path.join(tmpd, "enc_delta.pth"))
+    c1 = w.images_to_codes(img1)
+    shutil.rmtree(tmpd)
+    out["delta_codes"] = codes.numpy()
+    out["delta_img_before"], out["delta_img_after"] = img0.numpy(), img1.numpy()
+    out["delta_codes_before"], out["delta_codes_after"] = c0.numpy(), c1.numpy()
+    print("delta: max|dimg| %.4f, codes changed by the encoder patch: %d / %d" % (
+        float((img1 - img0).abs().max()), int((w.images_to_codes(img1) != c1).sum()), c1.numel()))
+    np.savez_compressed(os.path.join(HERE, "harness_vectors.npz"), **out)
+    print("wrote harness_vectors.npz", os.path.getsize(os.path.join(HERE, "harness_vectors.npz")), "bytes")
+    for k in ("job_files", "job_pvalue", "job_l0", "job_psnr"):
+        print(k, out[k])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--only", default="", help="'gumbel' / 'chameleon': regenerate only that fixture file")
+    ap.add_argument("--only", default="", help="'gumbel' / 'chameleon' / 'prod' / 'sampler' / 'harness': regenerate only that fixture file")
     args = ap.parse_args()
     if args.only == "gumbel":
         gumbel_vectors(args)
         return
-    if args.only == "chameleon":
+    if args.only in ("chameleon", "prod", "sampler", "harness"):
         tmp = tempfile.mkdtemp(prefix="wmar_stubs_")
         _stubs(tmp)
         sys.path[:0] = [tmp, args.ref, REPO]
         os.chdir(args.ref)
-        chameleon_vectors(args)
+        {"chameleon": chameleon_vectors, "prod": prod_vectors, "sampler": sampler_bulk_vectors, "harness": harness_vectors}[args.only](args)
         return
     tmp = tempfile.mkdtemp(prefix="wmar_stubs_")
     _stubs(tmp)
@@ -518,9 +824,12 @@ def main():
     rar_vectors(args, synth, wms, rs)
     gumbel_vectors(args)
     chameleon_vectors(args)
+    prod_vectors(args)
+    sampler_bulk_vectors(args)
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     sz = os.path.getsize(os.path.join(HERE, "reference_vectors.npz"))
     print("wrote reference_vectors.npz", sz, "bytes; key_kat.json")
+    harness_vectors(args)      # last: it plants placeholder modules for generate.py's unrelated imports
 
 
 if __name__ == "__main__":

@@ -131,3 +131,52 @@ def test_chameleon_7b_full_size_short_run():
     ns, ng = wm.detect_counts(a)[1:3]
     ns0, ng0 = wm.detect_counts(plain)[1:3]
     assert float(ng.sum()) / float(ns.sum()) > float(ng0.sum()) / float(ns0.sum())
+
+
+def test_chameleon_7b_real_workload_1024_tokens_vqgan512():
+    """BASELINE configs[3] at its real size: 7B transformer, batch 16 (48 sequences), 1024 image tokens, VQGAN-512 decode +
+    re-encode + detection.  Properties: the captured loop equals the eager loop on the first 64 tokens, a full replay is
+    deterministic, only image tokens are sampled, detector counts equal a host recount, images are [-1,1] 512x512."""
+    import time
+    from wmar_amd.models.chameleon_wrapper import ChameleonARMMWrapper
+    from wmar_amd.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
+    m = ChameleonARMMWrapper.synthetic(max_batch=16, logit_scale=8.0)
+    assert m.n_image_tokens == 1024 and m.image_size == 512
+    wm = GentimeWatermark(m.get_vq(), 65536, SeedStrategy.FIXED, SplitStrategy.RANDOM_STRATIFIED, 0, 2.0, 0.25, device="cuda")
+    m.set_watermarker(wm)
+    text = m.vocab.text_tokens
+    cond = [(i, [text[(i * 37 + j * 11) % len(text)] for j in range(8 + i % 7)]) for i in range(16)]
+    gp = {"temperature": 0.9, "top_p": 0.9}        # configs/chameleon_generate.json
+    torch.manual_seed(7)
+    q = m.draw_noise(16)
+    # first 64 tokens: captured loop == eager loop
+    full_n, shaped = m.n_image_tokens, m.is_codes_shaped
+    m.n_image_tokens, m.is_codes_shaped = 64, (lambda c: True)
+    q64 = q[:64].contiguous()
+    g64 = m.sample(cond, gp, apply_watermark=True, q=q64)
+    m.use_graph = False
+    e64 = m.sample(cond, gp, apply_watermark=True, q=q64)
+    m.use_graph = True
+    m.n_image_tokens = full_n
+    del m.is_codes_shaped
+    assert torch.equal(g64, e64)
+    # the whole image
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    a = m.sample(cond, gp, apply_watermark=True, q=q)
+    torch.cuda.synchronize(); t_gen = time.perf_counter() - t0
+    assert a.shape == (16, 1024) and torch.equal(a[:, :64], g64)
+    assert set(a.flatten().tolist()) <= set(m.vocab.image_tokens)
+    assert torch.equal(a, m.sample(cond, gp, apply_watermark=True, q=q))
+    pv, ns, ng = wm.detect_counts(a)
+    ref = _host_counts(wm.key_table_host().view(np.uint32), a.cpu().numpy(), h=0)
+    assert [(int(x), int(y)) for x, y in zip(ns.cpu(), ng.cpu())] == ref
+    plain = m.sample(cond, gp, apply_watermark=False, q=q)
+    ns0, ng0 = wm.detect_counts(plain)[1:3]
+    assert float(ng.sum()) / float(ns.sum()) > float(ng0.sum()) / float(ns0.sum()) + 0.02
+    assert float(pv.median()) < float(wm.detect(plain).median())
+    img = m.codes_to_images(a)
+    assert img.shape == (16, 3, 512, 512) and float(img.abs().max()) <= 1.0 + 1e-6 and torch.isfinite(img).all()
+    c2 = m.images_to_codes(img)
+    assert c2.shape == (16, 1024) and set(c2.flatten().tolist()) <= set(m.vocab.image_tokens)
+    assert torch.equal(c2, m.images_to_codes(img))
+    print(f"chameleon-7b b16: 1024 tokens in {t_gen:.2f} s ({t_gen / 1024 * 1e3:.2f} ms/step)")

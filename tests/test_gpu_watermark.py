@@ -173,3 +173,23 @@ def test_detector_short_raises(kat):
     wm = _wm(kat["keys"]["taming"])
     with pytest.raises(ValueError):
         wm.detect(torch.tensor([[3]]))
+
+
+def test_process_logits_empty_past_is_a_no_op(kat):
+    """RAR.generate calls the processor at step 0 with ids of shape [B, 0] (rar.py:420,451): the reference catches the
+    per-row ValueError and leaves the logits alone (gentime_watermark.py:266-269); FIXED seeding needs no context and still biases."""
+    rs = np.random.RandomState(0)
+    lg = torch.from_numpy(rs.randn(3, 1024).astype(np.float32)).cuda()
+    empty = torch.zeros(3, 0, dtype=torch.int64, device="cuda")
+    for seed, h in (("linear", 1), ("linear", 2), ("spatial", 1)):
+        wm = _wm(kat["keys"]["rar"], seed=seed, h=h)
+        out = wm.spawn_logit_processor()(past_ids=empty, logits=lg.clone())
+        assert torch.equal(out, lg), (seed, h)
+    wm = _wm(kat["keys"]["rar"], seed="fixed", h=0)
+    out = wm.spawn_logit_processor()(empty, lg.clone())        # positional call, as HF's LogitsProcessorList does
+    d = (out - lg).cpu().numpy()
+    assert set(np.unique(d).tolist()) == {0.0, 2.0} and int((d[0] == 2.0).sum()) == 256
+    # short-but-not-empty context under h = 2 is skipped too
+    wm = _wm(kat["keys"]["rar"], seed="linear", h=2)
+    one = torch.zeros(3, 1, dtype=torch.int64, device="cuda")
+    assert torch.equal(wm.spawn_logit_processor()(past_ids=one, logits=lg.clone()), lg)

@@ -524,9 +524,13 @@ extern "C" {
 
 int wmar_wm_process_logits(const wmar_wm_ctx* wm, float* logits_dev, int64_t B, const int64_t* past_ids_dev,
                            int64_t t, int64_t past_stride, void* stream) {
-    WMAR_REQUIRE(wm && logits_dev && (past_ids_dev || wm->seed_strategy == WMAR_SEED_FIXED), "process_logits: null argument");
+    // an EMPTY past (t == 0, e.g. RAR's first step: ids of shape [B, 0], rar.py:420,451) has no context: the reference catches
+    // the ValueError per row and leaves the logits alone (gentime_watermark.py:266-269), so a null pointer with t == 0 is legal
+    WMAR_REQUIRE(wm && logits_dev && (past_ids_dev || t == 0 || wm->seed_strategy == WMAR_SEED_FIXED), "process_logits: null argument");
+    WMAR_REQUIRE(t >= 0, "process_logits: negative context length");
     if (int rc = check_wm(wm, wm->vocab_size)) return rc;
     if (B == 0) return WMAR_OK;
+    if (!past_ids_dev && wm->seed_strategy != WMAR_SEED_FIXED) return WMAR_OK;   // every row skipped
     WmDev d = make_wm(wm);
     long long words = d.row_words;
     dim3 grid((unsigned)((words + 255) / 256), (unsigned)B);
@@ -544,7 +548,8 @@ int wmar_sample_fused(const wmar_wm_ctx* wm, const float* logits_dev, int64_t B,
     WMAR_REQUIRE(!(top_p >= 0) || top_p <= 1.0, "`top_p` has to be a float > 0 and < 1, but is %f", top_p);
     if (wm) {
         if (int rc = check_wm(wm, V)) return rc;
-        WMAR_REQUIRE(past_ids_dev || wm->seed_strategy == WMAR_SEED_FIXED, "sample_fused: past_ids required");
+        WMAR_REQUIRE(past_ids_dev || t == 0 || wm->seed_strategy == WMAR_SEED_FIXED, "sample_fused: past_ids required");
+        if (!past_ids_dev && wm->seed_strategy != WMAR_SEED_FIXED) wm = nullptr;   // empty past: no row has a context (rows skipped)
     }
     if (B == 0) return WMAR_OK;
     SampArgs a{};

@@ -95,7 +95,7 @@ def compute_metrics_and_save_from_batch_log(log, outdir, watermarker, eval_param
                                                                   watermarker, transform, param, compressors=compressors)
                     cond_index = cond_indices[i]
                     results.append(dict(conditioning=conditioning, idx=cond_index, method=method, transform=transform,
-                                        param=param, metrics=metrics))
+                                        param=param, metrics=metrics, codes=np.asarray(code, dtype=np.int64)))
                     if outdir is None:
                         continue
                     if not eval_params["orig_only"]:
@@ -138,6 +138,8 @@ def generate(outdir, model, all_inputs, watermarker, eval_params, gen_params, ch
         t_start = time.time()
         codes = model.sample(batch, gen_params, apply_watermark=watermarker is not None)
         all_codes = {str(watermarker): codes}
+        if codes.is_cuda:       # generation is enqueued asynchronously (hipGraph replays): wait before reading the clock
+            torch.cuda.synchronize(codes.device)
         sample_s = time.time() - t_start
         batch_log = {"batch": batch}
         for key, cd in all_codes.items():
@@ -151,10 +153,73 @@ def generate(outdir, model, all_inputs, watermarker, eval_params, gen_params, ch
     return results
 
 
+_REC_COLS = 9   # batch_idx, conditioning, idx, combo, pvalue, l0, psnr, sample_seconds, has-metric bits
+
+
+def _combos(eval_params):
+    """(transform, param) pairs in the order fill_batch_log produces them -- identical on every rank."""
+    out = [("roundtrips", T) for T in range(0, eval_params["max_roundtrips"] + 1)]
+    for aug_name, _, aug_params in eval_params.get("augmentations", []):
+        out += [(aug_name, p) for p in aug_params]
+    return out
+
+
+def gather_records(recs, eval_params, device, dst=0):
+    """The per-image results of all ranks on rank `dst`, exchanged as TENSORS with ``all_gather`` (RCCL over xGMI when the process
+    group is "nccl"; SURVEY 8e: codes int64[n, L], p-values f64[n], plus the bookkeeping columns) -- no pickling on the data path.
+    Method names and the (transform, param) table are the same on every rank and are not sent."""
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    combos = _combos(eval_params)
+    index = {(t, str(p)): i for i, (t, p) in enumerate(combos)}
+    n = len(recs)
+    L = max([len(r["codes"]) for r in recs], default=0)
+    meta = torch.tensor([n, L], dtype=torch.int64, device=device)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    n_max = max(int(m[0]) for m in metas)
+    L_max = max(int(m[1]) for m in metas)
+    rows = torch.zeros(n_max, _REC_COLS, dtype=torch.float64)
+    codes = torch.zeros(n_max, max(L_max, 1), dtype=torch.int64)
+    for i, r in enumerate(recs):
+        m = r["metrics"]
+        bits = sum(1 << j for j, k in enumerate(("pvalue", "l0", "psnr")) if m.get(k) is not None)
+        cond = r["conditioning"]
+        rows[i] = torch.tensor([r["batch_idx"], float(cond), r["idx"], index[(r["transform"], str(r["param"]))],
+                                m["pvalue"] if bits & 1 else 0.0, m["l0"] if bits & 2 else 0.0, m["psnr"] if bits & 4 else 0.0,
+                                r["sample_seconds"], bits], dtype=torch.float64)
+        codes[i, :len(r["codes"])] = torch.from_numpy(r["codes"])
+    rows, codes = rows.to(device), codes.to(device)
+    all_rows = [torch.zeros_like(rows) for _ in range(world)]
+    all_codes = [torch.zeros_like(codes) for _ in range(world)]
+    dist.all_gather(all_rows, rows)
+    dist.all_gather(all_codes, codes)
+    if rank != dst:
+        return None
+    method = recs[0]["method"] if recs else None
+    out = []
+    for w in range(world):
+        nw, Lw = int(metas[w][0]), int(metas[w][1])
+        rw, cw = all_rows[w].cpu(), all_codes[w].cpu()
+        for i in range(nw):
+            bits = int(rw[i, 8])
+            t, p = combos[int(rw[i, 3])]
+            metrics = {k: (float(rw[i, 4 + j]) if bits & (1 << j) else None) for j, k in enumerate(("pvalue", "l0", "psnr"))}
+            metrics = {k: v for k, v in metrics.items() if k in eval_params["metric_names"]}
+            out.append(dict(conditioning=int(rw[i, 1]), idx=int(rw[i, 2]), method=method, transform=t, param=p, metrics=metrics,
+                            codes=cw[i, :Lw].numpy().copy(), batch_idx=int(rw[i, 0]), sample_seconds=float(rw[i, 7])))
+    if method is None:
+        for r in out:
+            r.pop("method")
+    out.sort(key=lambda r: (r["batch_idx"], r["idx"], r["transform"], str(r["param"])))
+    return out
+
+
 def generate_sharded(outdir, model, all_inputs, watermarker, eval_params, gen_params, seed: int):
     """One process per GPU: rank r == the reference's ``--chunk_id r --num_chunks world_size``
     (generate.py:204 batch striping, :304 seed offset).  No data-path collective; the result
-    records are gathered on rank 0."""
+    records (codes, p-values, l0, psnr) are all-gathered as tensors and assembled on rank 0."""
     import torch.distributed as dist
 
     rank = dist.get_rank() if dist.is_initialized() else 0
@@ -163,10 +228,26 @@ def generate_sharded(outdir, model, all_inputs, watermarker, eval_params, gen_pa
     recs = generate(outdir, model, all_inputs, watermarker, eval_params, gen_params, chunk_id=rank, num_chunks=world)
     if world == 1:
         return recs
-    gathered: List[Optional[list]] = [None] * world if rank == 0 else None
-    dist.gather_object(recs, gathered, dst=0)
-    if rank != 0:
-        return None
-    out = [r for part in gathered for r in part]
-    out.sort(key=lambda r: (r["batch_idx"], r["idx"], r["transform"], str(r["param"])))
-    return out
+    for r in recs:          # the method string is rank-independent; conditioning of a prompt tuple is its index
+        if isinstance(r["conditioning"], tuple):
+            r["conditioning"] = r["conditioning"][0]
+    dev = model.device if dist.get_backend() == "nccl" else torch.device("cpu")
+    return gather_records(recs, eval_params, dev)
+
+
+def broadcast_key_table(watermarker, device, src=0):
+    """Build the key table once (rank `src`: MT19937 + Fisher-Yates over all context sums on the host cores) and broadcast the
+    finished bitmap (RCCL broadcast on "nccl"): 32 MiB for Taming h=1 instead of `world` rebuilds."""
+    import torch.distributed as dist
+
+    if dist.get_rank() == src:
+        table = watermarker.key_table()
+        shape = torch.tensor(list(table.shape), dtype=torch.int64, device=device)
+    else:
+        shape = torch.zeros(2, dtype=torch.int64, device=device)
+    dist.broadcast(shape, src)
+    if dist.get_rank() != src:
+        table = torch.empty(tuple(shape.tolist()), dtype=torch.int32, device=device)
+    dist.broadcast(table, src)
+    watermarker.set_key_table(table)
+    return table

@@ -49,6 +49,18 @@ class AutoregressiveMultimodalModelWrapper:
     def device(self):
         return self.model.device
 
+    # Where the Exp(1) noise of ``torch.multinomial`` is drawn.  None: the model's device (what the reference does when the
+    # model lives on the GPU).  "cpu": the CPU default generator, copied to the device -- reproduces a reference run whose
+    # model (and therefore whose ``multinomial`` call) was on the CPU, e.g. the committed golden fixtures.
+    noise_device = None
+
+    def _noise_draw(self, fn, shape, generator=None):
+        """`fn` fills a fresh float32 tensor of `shape` in place on the noise device; returns it on the model's device."""
+        dev = torch.device(self.noise_device) if self.noise_device is not None else torch.device(self.model.device)
+        t = torch.empty(shape, dtype=torch.float32, device=dev)
+        fn(t, generator)
+        return t if dev == torch.device(self.model.device) else t.to(self.model.device)
+
     def init_alivecodes(self, alive_ids_path):
         """Attach ``alive_ids`` (file order) and ``dead_ids`` to the quantizer.  The dead list is
         ``list(set(range(V)) - set(alive))`` exactly as armm_wrapper.py:42-55 builds it: its ORDER feeds the key derivation."""

@@ -42,6 +42,16 @@ def allow_bitmap(ids: Sequence[int], vocab_size: int, device) -> torch.Tensor:
     return torch.from_numpy(bits.view(np.int32)).to(device)
 
 
+def eight_bit_round_trip(images: torch.Tensor) -> torch.Tensor:
+    """What the reference's ``images_to_codes`` does to the pixels before the VQGAN sees them (chameleon_wrapper.py:177-181):
+    ``ImageTokenizer._pil_from_chw_tensor`` (image_tokenizer.py:100-122: clamp, (x+1)/2, *255, TRUNCATING uint8 cast) and
+    ``_vqgan_input_from`` (:74-93: the 512x512 image passes resize / centre crop unchanged, then uint8/255 in float64, *2-1,
+    float32).  Pure tensor ops on the tensor's own device -- no PIL image, no host copy."""
+    x = (torch.clamp(images.to(torch.float32), -1.0, 1.0) + 1.0) / 2.0
+    u8 = (x * 255).to(torch.uint8)
+    return (u8.to(torch.float64) / 255.0 * 2 - 1).to(torch.float32)
+
+
 class ChameleonARMMWrapper(AutoregressiveMultimodalModelWrapper):
     n_image_tokens = 1024
 
@@ -157,7 +167,7 @@ class ChameleonARMMWrapper(AutoregressiveMultimodalModelWrapper):
         V = self.model.cfg.vocab_size
         q = torch.empty(self.n_image_tokens, B, V, dtype=torch.float32, device=self.model.device)
         for n in range(self.n_image_tokens):
-            q[n].exponential_(1, generator=generator)
+            q[n].copy_(self._noise_draw(lambda t, g: t.exponential_(1, generator=g), (B, V), generator))
         return q
 
     # conditioning: list of (index, prompt) tuples (prompt: str, or a list of token ids); gen_params: {top_p, temperature}
@@ -195,9 +205,7 @@ class ChameleonARMMWrapper(AutoregressiveMultimodalModelWrapper):
     # images -> BPE ids; the reference goes through an 8-bit PIL image (truncating cast, image_tokenizer.py:100-122, :74-86)
     def images_to_codes(self, images):
         assert self.is_images_shaped(images), f"Images shape: {images.shape}"
-        x = (torch.clamp(images.to(self.model.device, torch.float32), -1.0, 1.0) + 1.0) / 2.0
-        u8 = (x * 255).to(torch.uint8)
-        x = (u8.to(torch.float64) / 255.0 * 2 - 1).to(torch.float32)
+        x = eight_bit_round_trip(images.to(self.model.device))
         codes = self.translation.convert_img2bp2(self.vq_engine.encode(x)).to(torch.int64)
         assert self.is_codes_shaped(codes), f"Codes shape: {codes.shape}"
         return codes

@@ -103,10 +103,10 @@ class RarARMMWrapper(AutoregressiveMultimodalModelWrapper):
         """The draws of RAR.generate on the default generator, in order: the label-drop mask of
         preprocess_condition (rar.py:305) then one [B,V] Exp(1) tensor per step (multinomial, :454)."""
         cfg = self.model.cfg
-        torch.rand(B, 1, dtype=torch.float, device=self.model.device, generator=generator)
+        self._noise_draw(lambda t, g: t.uniform_(0, 1, generator=g), (B, 1), generator)   # == torch.rand(B, 1) on that stream
         q = torch.empty(cfg.image_seq_len, B, cfg.codebook_size, dtype=torch.float32, device=self.model.device)
         for n in range(cfg.image_seq_len):
-            q[n].exponential_(1, generator=generator)
+            q[n].copy_(self._noise_draw(lambda t, g: t.exponential_(1, generator=g), (B, cfg.codebook_size), generator))
         return q
 
     # conditioning: list of size [b] of class indices; gen_params ignored (as in the reference)

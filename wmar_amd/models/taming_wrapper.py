@@ -176,7 +176,7 @@ class TamingARMMWrapper(AutoregressiveMultimodalModelWrapper):
         V = self.model.gpt_cfg.vocab_size
         q = torch.empty(steps, B, V, dtype=torch.float32, device=self.model.device)
         for n in range(steps):
-            q[n].exponential_(1, generator=generator)
+            q[n].copy_(self._noise_draw(lambda t, g: t.exponential_(1, generator=g), (B, V), generator))
         return q
 
     # conditioning: list of size [b]; gen_params: dict; returns detached codes [b, codes_size**2]

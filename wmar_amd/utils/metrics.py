@@ -10,7 +10,7 @@ import torch
 def compute_psnr(a, b, M=255.0):
     """PSNR in dB between two PIL images (or uint8 arrays); identical images give +inf like the reference."""
     diff = np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)
-    mse = float(np.mean(diff * diff))
+    mse = np.mean(diff * diff)          # stays a numpy scalar: 0 divides to +inf (a Python float would raise)
     with np.errstate(divide="ignore"):
         return 10 * np.log10(M ** 2 / mse)
 

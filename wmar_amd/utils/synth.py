@@ -55,6 +55,10 @@ class VQConfig:
 
 TAMING_GPT = GPTConfig()
 TAMING_VQ = VQConfig()
+# the reduced Taming model the reference's own generate.py was run on for tests/golden/harness_vectors.npz (seeds 21)
+HARNESS_GPT = dict(vocab_size=16384, block_size=64, n_layer=2, n_head=4, n_embd=128)
+HARNESS_VQ = dict(ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(8,), resolution=32, z_channels=16, embed_dim=8,
+                  n_embed=16384)
 
 
 def gpt_shapes(cfg: GPTConfig, with_mask: bool = False) -> Dict[str, Tuple[int, ...]]:
@@ -530,3 +534,19 @@ def synth_chameleon_vocab(n_vocab: int = 65536, n_img: int = 8192, first_img: in
         nxt += 1
         i += 1
     return vm
+
+
+def synth_delta(state: Dict[str, torch.Tensor], prefix: str, seed: int = 0, scale: float = 0.02,
+                every: int = 3) -> Dict[str, torch.Tensor]:
+    """A ``*_delta.pth``-style patch (wmar/utils/utils.py:47-66) for the sub-module `prefix` ("encoder." / "decoder."):
+    seeded perturbations of every `every`-th tensor, keyed RELATIVE to the sub-module like the released delta checkpoints."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed + 31337)
+    out = {}
+    keys = sorted(k for k in state if k.startswith(prefix))
+    for i, k in enumerate(keys):
+        if i % every:
+            continue
+        t = state[k]
+        out[k[len(prefix):]] = (torch.randn(t.shape, generator=g) * scale * float(t.abs().mean().clamp_min(1e-3))).to(torch.float32)
+    return out

@@ -15,6 +15,7 @@ The device functions need an MI355X (``device="cuda..."``); there is no CPU path
 from __future__ import annotations
 
 import ctypes as C
+import collections
 import hashlib
 from enum import Enum
 from functools import partial
@@ -41,7 +42,23 @@ class SplitStrategy(Enum):
 _SEED_CODE = {SeedStrategy.FIXED: 0, SeedStrategy.LINEAR: 1, SeedStrategy.SPATIAL: 2}
 _SPLIT_CODE = {SplitStrategy.RANDOM: 0, SplitStrategy.RANDOM_STRATIFIED: 1}
 
-_TABLE_CACHE: dict = {}
+# Device key tables shared by watermarkers with the same key (a sweep over delta re-uses one table).  Bounded: a sweep over
+# gamma / h / salt would otherwise pin tens to hundreds of MiB of HBM per configuration for the life of the process.  An evicted
+# table stays alive as long as a watermarker still references it.
+_TABLE_CACHE: "collections.OrderedDict" = collections.OrderedDict()
+_TABLE_CACHE_MAX = 4
+
+
+def clear_key_cache():
+    """Drop every cached device key table (they are rebuilt on next use)."""
+    _TABLE_CACHE.clear()
+
+
+def _cache_put(key, table):
+    _TABLE_CACHE[key] = table
+    _TABLE_CACHE.move_to_end(key)
+    while len(_TABLE_CACHE) > _TABLE_CACHE_MAX:
+        _TABLE_CACHE.popitem(last=False)
 
 
 def _is_cuda(device) -> bool:
@@ -158,14 +175,16 @@ class GentimeWatermark:
             ck = self._cache_key()
             if ck not in _TABLE_CACHE:
                 host = torch.from_numpy(self.key_table_host().view(np.int32))
-                _TABLE_CACHE[ck] = host.to(self.device)
+                _cache_put(ck, host.to(self.device))
+            else:
+                _TABLE_CACHE.move_to_end(ck)
             self._table = _TABLE_CACHE[ck]
         return self._table
 
     def set_key_table(self, table: torch.Tensor):
         """Install a table received from another rank (RCCL broadcast) instead of rebuilding it."""
         self._table = table
-        _TABLE_CACHE[self._cache_key()] = table
+        _cache_put(self._cache_key(), table)
 
     def wm_ctx(self) -> _lib.WmCtx:
         t = self.key_table()
