@@ -2,7 +2,8 @@
 
 One "step" = one pass of the hot path over one batch of synthetic class labels:
     sample 256 tokens (Taming cin_transformer, greenlist watermark delta=2 gamma=.25 h=1,
-    T=1, top-k 250, top-p .92)  ->  codes_to_images  ->  images_to_codes  ->  detect.
+    T=1, top-k 250, top-p .92)  ->  codes_to_images  ->  images_to_codes  ->  detect
+(and, with more than one rank, the all_gather of codes / counts / p-values: SURVEY 8e's one exchange step).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -10,10 +11,16 @@ One "step" = one pass of the hot path over one batch of synthetic class labels:
 
 Weights are seeded random-init tensors of the real architecture (no checkpoints offline);
 inputs are resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
+
+Test hook (tests/test_bench_distributed_cpu.py): WMAR_BENCH_BACKEND=gloo + WMAR_BENCH_ENGINE="module:factory" run the SAME
+control flow (process group, key broadcast, barriers, max-over-ranks timing, gather, JSON line) on CPU with a stand-in engine;
+the product engines have no CPU path and the default factory fails loudly without an MI355X.
 """
 import argparse
+import importlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -26,11 +33,12 @@ B = 64
 GEN = dict(batch_size=B, temperature=1.0, top_k=250, top_p=0.92)
 PEAK_F32_MFMA_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E spec
+METRIC = "watermarked images/sec at 256x256 (16x16 tok), batch 64; detector p-value delta vs ref"
 
 
 def usable_cores() -> int:
     """Host threads this process may really use: scheduler affinity capped by the cgroup CPU
-    quota, and by 32 (the oracle's batch-8 GEMMs stop scaling long before that; 256 threads on
+    quota, and by 32 (the oracle's GEMMs stop scaling long before that; 256 threads on
     the GPU box's host measured 200x SLOWER than 8)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
@@ -42,11 +50,22 @@ def usable_cores() -> int:
     return max(1, min(n, 32))
 
 
-def cpu_baseline(gpt_state_gpu, vq_state_gpu, gcfg, vcfg, wm, log):
-    """The CPU oracle (a port of the reference's path, parity-pinned in tests/) timed on this
-    host's cores on a bounded sample of the SAME workload: 6 decode steps of the full 48-layer
-    model at batch 8 with watermark + sampling (extrapolated to 256 steps), VQGAN decode+encode
-    of 2 images, detection of 8 images."""
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(gpt_state_gpu, vq_state_gpu, gcfg, vcfg, wm, log, budget_s=75.0):
+    """the CPU oracle (a port of the reference's path, parity-pinned in tests/) on this host's cores,
+    fp32, on the two stated configurations -- Taming batch 1 (configs[0]) and batch 64 (configs[1]) -- with the stages timed
+    separately: `sample` = 16 decode steps of the full 48-layer model incl. watermark + top-k/top-p + multinomial, extrapolated
+    x16 to 256 steps (stated in `sample`); codes_to_images / images_to_codes on 2 images; detect on 64.  3 repeats after one
+    warm-up, median and spread reported; repeats are cut (and said so) if the leg would exceed its time budget."""
     from oracle import model_oracle as M
     from oracle import wm_oracle as W
 
@@ -55,35 +74,190 @@ def cpu_baseline(gpt_state_gpu, vq_state_gpu, gcfg, vcfg, wm, log):
     gs = {k: v.cpu() for k, v in gpt_state_gpu.items()}
     vs = {k: v.cpu() for k, v in vq_state_gpu.items()}
     key = W.KeyParams(wm._alive_host, wm._dead_host, gcfg.vocab_size, wm.gamma)
-    Bc, nsteps = 8, 6
-    cond = torch.tensor([(i * 37) % 1000 for i in range(Bc)]).view(-1, 1)
-    torch.manual_seed(0)
-    t0 = time.perf_counter()
-    M.sample_with_past(gs, gcfg.n_head, cond, 1, 1.0, 250, 0.92, key, 2.0)  # warm-up (thread pools, oracle .so)
-    warm = time.perf_counter() - t0
-    if warm > 6.0:  # slow host: keep the whole leg bounded, reuse the first step's time
-        nsteps, t_step = 1, warm
-    else:
-        if warm > 2.0:
-            nsteps = max(1, int(12.0 / warm))
+    S = vcfg.codes_size ** 2
+    NSTEP = 16
+    t_begin = time.perf_counter()
+
+    def timed(fn, reps):
+        out = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            out.append(time.perf_counter() - t0)
+        return out
+
+    def sample_cfg(Bc):
+        cond = torch.tensor([(i * 37) % 1000 for i in range(Bc)]).view(-1, 1)
+        torch.manual_seed(1)
+        run = lambda n: M.sample_with_past(gs, gcfg.n_head, cond, n, 1.0, 250, 0.92, key, 2.0)
         t0 = time.perf_counter()
-        M.sample_with_past(gs, gcfg.n_head, cond, nsteps, 1.0, 250, 0.92, key, 2.0)
-        t_step = (time.perf_counter() - t0) / nsteps
-    nvq = 2 if warm < 4.0 else 1
-    full = torch.randint(0, gcfg.vocab_size, (nvq, vcfg.codes_size ** 2))
-    t0 = time.perf_counter()
-    img = M.codes_to_images(vs, vcfg, full)
-    c2 = M.images_to_codes(vs, vcfg, img)
-    t_vq = (time.perf_counter() - t0) / nvq
-    det_codes = torch.randint(0, gcfg.vocab_size, (Bc, vcfg.codes_size ** 2)).numpy()
-    t0 = time.perf_counter()
-    W.detect(key, det_codes)
-    t_det = (time.perf_counter() - t0) / Bc
-    per_img = t_step * (vcfg.codes_size ** 2) / Bc + t_vq + t_det
-    log(f"cpu_baseline: {t_step:.3f} s/step @B={Bc}, vq {t_vq:.2f} s/img, detect {t_det*1e3:.1f} ms/img, {cores} threads")
-    return {"value": 1.0 / per_img, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{nsteps} decode steps of the full 48L model at batch {Bc} incl. watermark+sampling "
-                      f"(x{vcfg.codes_size ** 2}/{nsteps} extrapolated), VQGAN decode+encode of {nvq} images, detect of {Bc}"}
+        run(1)                                                  # warm-up (thread pools, oracle .so)
+        warm = time.perf_counter() - t0
+        left = budget_s * (0.25 if Bc == 1 else 0.55)
+        reps = 3 if warm * NSTEP * 3 < left else 1
+        nstep = NSTEP if warm * NSTEP * reps < left * 1.5 else max(1, int(left / max(warm, 1e-3)))
+        ts = [t / nstep for t in timed(lambda: run(nstep), reps)]
+        return {"s_per_step": statistics.median(ts), "min": min(ts), "max": max(ts), "repeats": reps, "steps_timed": nstep}
+
+    b1 = sample_cfg(1)
+    b64 = sample_cfg(B)
+    nvq = 2
+    full = torch.randint(0, gcfg.vocab_size, (nvq, S))
+    img = M.codes_to_images(vs, vcfg, full)                    # warm-up
+    vq_reps = 3 if (time.perf_counter() - t_begin) < budget_s * 0.8 else 1
+    t_dec = statistics.median(timed(lambda: M.codes_to_images(vs, vcfg, full), vq_reps)) / nvq
+    t_enc = statistics.median(timed(lambda: M.images_to_codes(vs, vcfg, img), vq_reps)) / nvq
+    det_codes = torch.randint(0, gcfg.vocab_size, (B, S)).numpy()
+    W.detect(key, det_codes[:2])
+    t_det = statistics.median(timed(lambda: W.detect(key, det_codes), 3)) / B
+    per_img_64 = b64["s_per_step"] * S / B + t_dec + t_enc + t_det
+    per_img_1 = b1["s_per_step"] * S + t_dec + t_enc + t_det
+    log(f"cpu_baseline: B=1 {b1['s_per_step']:.3f} s/step, B=64 {b64['s_per_step']:.3f} s/step, vq decode {t_dec:.2f} + encode {t_enc:.2f} s/img, "
+        f"detect {t_det * 1e3:.1f} ms/img, {cores} threads, {time.perf_counter() - t_begin:.0f} s")
+    r3 = lambda x: round(x, 4)
+    return {"value": 1.0 / per_img_64, "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "sample": f"Taming batch 64 (configs[1]): {b64['steps_timed']} decode steps of the full 48L model incl. watermark + sampling, "
+                      f"{b64['repeats']} repeats (median; x{S}/{b64['steps_timed']} extrapolated to {S} steps), VQGAN decode + encode of "
+                      f"{nvq} images ({vq_reps} repeats), detect of {B}; batch 1 (configs[0]) timed the same way",
+            "batch64": {"images_per_s": 1.0 / per_img_64, "sample_s_per_step": r3(b64["s_per_step"]),
+                        "sample_s_per_step_min_max": [r3(b64["min"]), r3(b64["max"])], "sample_s_per_image": r3(b64["s_per_step"] * S / B)},
+            "batch1": {"images_per_s": 1.0 / per_img_1, "sample_s_per_step": r3(b1["s_per_step"]),
+                       "sample_s_per_step_min_max": [r3(b1["min"]), r3(b1["max"])], "sample_s_per_image": r3(b1["s_per_step"] * S)},
+            "codes_to_images_s_per_image": r3(t_dec), "images_to_codes_s_per_image": r3(t_enc), "detect_s_per_image": round(t_det, 6)}
+
+
+def parity_block(log):
+    """The 'p-value delta vs ref' half of the metric, computed OUTSIDE the timed region on the committed reference fixtures
+    (tests/golden/*.npz: outputs of the reference itself): token mismatches of the 256-step watermarked loop at production
+    width, detector p-values of those tokens, decoded pixels of the golden VQGAN.  Data files only -- no oracle involved."""
+    import numpy as np
+    from wmar_amd.models.engine import GPTEngine, VQGANEngine
+    from wmar_amd.utils import synth
+    from wmar_amd.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
+
+    gdir = os.path.join(ROOT, "tests", "golden")
+    pv = np.load(os.path.join(gdir, "prod_vectors.npz"))
+    gv = np.load(os.path.join(gdir, "reference_vectors.npz"))
+    gcfg = synth.GPTConfig(vocab_size=16384, block_size=256, n_layer=2, n_head=24, n_embd=1536)
+    eng = GPTEngine(gcfg, synth.synth_gpt_state(gcfg, seed=9, logit_scale=10.0), max_batch=64)
+    ids = []
+    for line in open(os.path.join(ROOT, "wmar_amd", "assets", "vqgan_alive_ids.txt")):
+        ids.extend(int(t) for t in line.split(","))
+    dead = sorted(set(range(16384)) - set(ids))
+    wm = GentimeWatermark({"alive_ids": torch.tensor(ids), "dead_ids": torch.tensor(dead), "embedding": None}, 16384,
+                          SeedStrategy.LINEAR, SplitStrategy.RANDOM_STRATIFIED, 1, 2.0, 0.25, device="cuda")
+    torch.manual_seed(11)
+    q = torch.stack([torch.empty(4, 16384).exponential_(1) for _ in range(256)]).cuda()
+    toks = eng.generate(torch.from_numpy(pv["loop_cond"]).view(-1).cuda(), 256, q, 1.0, 250, 0.92, wm.wm_ctx())
+    ref = torch.from_numpy(pv["loop_tokens"].astype(np.int64))
+    mism = int((toks.cpu() != ref).sum())
+    p = wm.detect(ref.cuda()).cpu().numpy()                    # detector on the reference's own tokens
+    dlog = float(np.abs(np.log10(p) - np.log10(pv["loop_pvals"])).max())
+    dabs = float(np.abs(p - pv["loop_pvals"]).max())
+    seq = torch.from_numpy(pv["gpt_seq"].astype(np.int64)).cuda()
+    dlogit = 0.0
+    for t in range(2):
+        lg = eng.decode_step(seq[:, t], t)
+        dlogit = max(dlogit, float(np.abs(lg[:, ::64].cpu().numpy() - pv["gpt_logits"][t]).max()))
+    vcfg = synth.VQConfig(ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(8,), resolution=32, z_channels=16,
+                          embed_dim=8, n_embed=512)
+    vq = VQGANEngine(vcfg, synth.synth_vq_state(vcfg, seed=5), max_batch=4)
+    img = vq.decode(torch.from_numpy(gv["vq_codes"]).cuda()).cpu().numpy()
+    dpix = float(np.abs(img - gv["vq_images"]).max())
+    codes2 = vq.encode(torch.from_numpy(gv["vq_images"]).cuda()).cpu().numpy()
+    out = {"reference_fixture": "tests/golden/prod_vectors.npz + reference_vectors.npz (outputs of the reference's own code)",
+           "token_mismatches": mism, "tokens_compared": int(ref.numel()), "max_abs_dlog10_pvalue": dlog, "max_abs_dpvalue": dabs,
+           "max_abs_dlogit": dlogit, "max_abs_dpixel": dpix,
+           "reencoded_code_mismatches": int((codes2 != gv["vq_codes_roundtrip"]).sum()), "codes_compared": int(codes2.size)}
+    log(f"parity: {out}")
+    return out
+
+
+def default_engine(device, rank, args):
+    """The product path: HIP engines on an MI355X (fails loudly anywhere else)."""
+    from wmar_amd.models.taming_wrapper import TamingARMMWrapper
+    from wmar_amd.utils import synth
+    from wmar_amd.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X: the wmar_amd engines have no CPU implementation")
+    gcfg, vcfg = synth.TAMING_GPT, synth.TAMING_VQ
+    gs = synth.synth_gpt_state_fast(gcfg, 0, device, logit_scale=30.0)
+    vs = synth.synth_vq_state_fast(vcfg, 0, device)
+    model = TamingARMMWrapper(None, gpt_cfg=gcfg, vq_cfg=vcfg, gpt_state=gs, vq_state=vs, device=device, max_batch=B)
+    model.use_graph = not args.no_graph
+    wm = GentimeWatermark(model.get_vq(), gcfg.vocab_size, SeedStrategy.LINEAR, SplitStrategy.RANDOM_STRATIFIED, 1,
+                          2.0, 0.25, device=device)
+    return model, wm, dict(gs=gs, vs=vs, gcfg=gcfg, vcfg=vcfg)
+
+
+def gpu_analysis(model, wm, extra, cond, args, world, log):
+    """Rank 0, after the timed region: per-role kernel timings (HIP events on the launch stream), rooflines, stage split,
+    parity on the golden fixtures, CPU baseline."""
+    gcfg, vcfg = extra["gcfg"], extra["vcfg"]
+    eng = model.model.transformer
+    S = vcfg.codes_size ** 2
+    D, V, L = gcfg.n_embd, gcfg.vocab_size, gcfg.n_layer
+    # ---- every decode-step kernel role replayed back to back (cycling through the 48 layers, so weights and KV stream from
+    # HBM as in a real step) between two hipEvents on the launch stream
+    per_step = {"qkv": L, "attn": L, "proj": L, "resid": L + 1, "fc1": L, "fc2": L, "head": 1}
+    kv_avg = (S + 1) // 2
+    avg_us = {k: eng.profile_role(k, B, kv_len=kv_avg, iters=2 * L) for k in per_step}
+    flops = {"qkv": 2.0 * B * 3 * D * D, "proj": 2.0 * B * D * D, "fc1": 2.0 * B * 4 * D * D,
+             "fc2": 2.0 * B * 4 * D * D, "head": 2.0 * B * D * V}
+    attn_bytes = 2.0 * B * D * 4 * kv_avg                  # K and V rows of kv_avg cached tokens for every (sequence, head)
+    share = {k: avg_us[k] * per_step[k] for k in per_step}
+    tot = sum(share.values())
+    names = {"qkv": "k_qkvx<2,6> residual fold + LN1 statistics + QKV 1536->4608 (252 workgroups, split-K pieces)",
+             "attn": "k_attn_decode<64,1> decode attention, fp32 KV cache",
+             "fc1": "k_gemm<2,4,EPI_GELU,LN> 1536->6144 (FC1)", "fc2": "k_gemm<2,4,EPI_PACKED> 6144->1536 split-K (FC2)",
+             "proj": "k_gemm<2,4,EPI_PACKED> 1536->1536 split-K (proj)", "head": "k_gemm<2,4,EPI_LOGITS,LN> 1536->16384 (head)",
+             "resid": "k_resid_stats residual fold + LN2 statistics"}
+    roles = {}
+    for k in per_step:
+        r = {"kernel": names[k], "avg_us": round(avg_us[k], 2), "launches_per_step": per_step[k],
+             "share_of_decode_step": round(share[k] / tot, 3)}
+        if k in flops:
+            r.update(bound="mfma", achieved=round(flops[k] / avg_us[k] * 1e-6, 2), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s",
+                     flop_per_launch=flops[k])
+            r["frac"] = round(r["achieved"] / PEAK_F32_MFMA_TF, 4)
+        elif k == "attn":
+            r.update(bound="hbm", achieved=round(attn_bytes / avg_us[k] * 1e-3, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                     bytes_per_launch=attn_bytes, kv_len=kv_avg)
+            r["frac"] = round(r["achieved"] / PEAK_HBM_GBS, 4)
+        roles[k] = r
+    dom = max((k for k in roles if "frac" in roles[k]), key=lambda k: share[k])    # ALL roles, attention included
+    traffic = None
+    try:   # HBM bytes per launch from the committed PMC passes (separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", f"pmc_{dom}.json")))
+        traffic = pmc["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    roofline = {"bound": roles[dom]["bound"], "achieved": roles[dom]["achieved"], "peak": roles[dom]["peak"],
+                "unit": roles[dom]["unit"], "frac": roles[dom]["frac"], "traffic": traffic, "kernel": roles[dom]["kernel"],
+                "avg_us": roles[dom]["avg_us"], "launches_per_step": per_step[dom],
+                "algorithmic_per_launch": roles[dom].get("bytes_per_launch", roles[dom].get("flop_per_launch")),
+                "share_of_decode_step": roles[dom]["share_of_decode_step"], "role": dom}
+    gemm_tf = sum(flops[k] * per_step[k] for k in flops) / sum(share[k] for k in flops) * 1e-6
+    torch.cuda.synchronize()
+    t1 = time.perf_counter(); codes_t = model.sample(cond, GEN, True); torch.cuda.synchronize()
+    t2 = time.perf_counter(); im = model.codes_to_images(codes_t); torch.cuda.synchronize()
+    t3 = time.perf_counter(); c2 = model.images_to_codes(im); torch.cuda.synchronize()
+    t4 = time.perf_counter(); wm.detect_counts(c2); torch.cuda.synchronize()
+    t5 = time.perf_counter()
+    split = {"sample_s": round(t2 - t1, 4), "vq_decode_s": round(t3 - t2, 4), "vq_encode_s": round(t4 - t3, 4),
+             "detect_s": round(t5 - t4, 5)}
+    step_ms = split["sample_s"] / S * 1e3
+    # SURVEY 8d: per step max(1.13 ms fp32 MFMA, 1.30 ms HBM) at batch 64; per image 252.7 (decode) / 138.4 + 2.1 (encode) GFLOP
+    step_roofline_ms = max(2.0 * B * 1.38412e9 / (PEAK_F32_MFMA_TF * 1e12), (5.53648e9 + 2.0 * L * D * 4 * kv_avg * B) / (PEAK_HBM_GBS * 1e9)) * 1e3
+    out = {"roofline": roofline, "roofline_by_role": roles,
+           "decode_step": {"ms": round(step_ms, 3), "roofline_ms": round(step_roofline_ms, 3), "frac": round(step_roofline_ms / step_ms, 3),
+                           "gemm_TFLOPs_all_roles": round(gemm_tf, 2)},
+           "vqgan": {"decode_TFLOPs": round(252.7e9 * B / split["vq_decode_s"] * 1e-12, 1),
+                     "encode_TFLOPs": round(140.5e9 * B / split["vq_encode_s"] * 1e-12, 1), "peak": PEAK_F32_MFMA_TF},
+           "end_to_end_frac_of_roofline": None,
+           "stage_seconds_per_batch": split}
+    return out
 
 
 def main():
@@ -92,6 +266,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     args = ap.parse_args()
 
@@ -99,70 +274,78 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    backend = os.environ.get("WMAR_BENCH_BACKEND", "nccl")          # "nccl" IS RCCL on ROCm
+    on_gpu = backend == "nccl"
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}" if on_gpu else "cpu"
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl")  # RCCL over xGMI
+        dist.init_process_group(backend)  # RCCL over xGMI
 
     def log(msg):
         if rank == 0:
             print(msg, file=sys.stderr, flush=True)
 
-    from wmar_amd.models.taming_wrapper import TamingARMMWrapper
-    from wmar_amd.utils import synth
-    from wmar_amd.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
 
-    gcfg, vcfg = synth.TAMING_GPT, synth.TAMING_VQ
+    factory = default_engine
+    if os.environ.get("WMAR_BENCH_ENGINE"):
+        mod, fn = os.environ["WMAR_BENCH_ENGINE"].split(":")
+        factory = getattr(importlib.import_module(mod), fn)
     t0 = time.time()
-    gs = synth.synth_gpt_state_fast(gcfg, 0, device, logit_scale=30.0)
-    vs = synth.synth_vq_state_fast(vcfg, 0, device)
-    model = TamingARMMWrapper(None, gpt_cfg=gcfg, vq_cfg=vcfg, gpt_state=gs, vq_state=vs, device=device, max_batch=B)
-    model.use_graph = not args.no_graph
-    wm = GentimeWatermark(model.get_vq(), gcfg.vocab_size, SeedStrategy.LINEAR, SplitStrategy.RANDOM_STRATIFIED, 1,
-                          2.0, 0.25, device=device)
-    # the key table is built once (host MT19937) on rank 0 and broadcast over RCCL
+    model, wm, extra = factory(device, rank, args)
+    # the key table is built once (host MT19937 + Fisher-Yates over all context sums) on rank 0 and broadcast over RCCL
     if world > 1:
-        if rank == 0:
-            table = wm.key_table()
-        else:
-            table = torch.empty(gcfg.vocab_size, gcfg.vocab_size // 32, dtype=torch.int32, device=device)
-        dist.broadcast(table, 0)
-        wm.set_key_table(table)
+        from wmar_amd import harness
+        harness.broadcast_key_table(wm, device)
     else:
         wm.key_table()
     model.set_watermarker(wm)
-    _ = model.model.vq_engine
-    torch.cuda.synchronize()
-    log(f"setup {time.time() - t0:.1f}s; GPT engine {model.model.transformer.device_bytes / 1e9:.1f} GB, "
-        f"VQGAN engine {model.model.vq_engine.device_bytes / 1e9:.1f} GB")
+    if on_gpu:
+        _ = model.model.vq_engine
+        sync()
+        log(f"setup {time.time() - t0:.1f}s; GPT engine {model.model.transformer.device_bytes / 1e9:.1f} GB, "
+            f"VQGAN engine {model.model.vq_engine.device_bytes / 1e9:.1f} GB")
 
-    # weak scaling: every rank generates its own batch of 64 class labels (rank = the reference's chunk id)
+    # weak scaling: every rank generates its own batch of 64 class labels (rank = the reference's chunk id, generate.py:204,304)
     cond = torch.tensor([((rank * B + i) * 37) % 1000 for i in range(B)], device=device)
     torch.manual_seed(1 + 1000 * rank)
-    torch.cuda.manual_seed_all(1 + 1000 * rank)
+    if on_gpu:
+        torch.cuda.manual_seed_all(1 + 1000 * rank)
+
+    def gather(t):
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t.contiguous())
+        return torch.cat(outs)
 
     def step():
         codes = model.sample(cond, GEN, apply_watermark=True)
         imgs = model.codes_to_images(codes)
         codes2 = model.images_to_codes(imgs)
-        return wm.detect_counts(codes2), codes, codes2
+        pv, ns, ng = wm.detect_counts(codes2)
+        if world > 1:      # the path's one exchange step: codes int64[64,256], counts int32[64], p-values f64[64] per rank
+            codes2_all, ns_all, ng_all, pv_all = gather(codes2), gather(ns), gather(ng), gather(pv)
+            return (pv_all, ns_all, ng_all), codes, codes2, codes2_all
+        return (pv, ns, ng), codes, codes2, codes2
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        (pv, ns, ng), codes, codes2 = step()
-    torch.cuda.synchronize()
+        (pv, ns, ng), codes, codes2, codes2_all = step()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -170,77 +353,30 @@ def main():
         dt = float(tt.item())
     value = world * B * args.steps / dt
 
-    out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream:
-        # each decode-step kernel role is replayed back to back (cycling through the 48 layers, so
-        # weights stream from HBM as in a real step) between two hipEvents.
-        eng = model.model.transformer
-        S = vcfg.codes_size ** 2
-        D, V, L = gcfg.n_embd, gcfg.vocab_size, gcfg.n_layer
-        per_step = {"qkv": L, "attn": L, "proj": L, "resid": 2 * L + 1, "fc1": L, "fc2": L, "head": 1}
-        kv_avg = (S + 1) // 2
-        avg_us = {k: eng.profile_role(k, B, kv_len=kv_avg, iters=2 * L) for k in per_step}
-        flops = {"qkv": 2.0 * B * 3 * D * D, "proj": 2.0 * B * D * D, "fc1": 2.0 * B * 4 * D * D,
-                 "fc2": 2.0 * B * 4 * D * D, "head": 2.0 * B * D * V}
-        share = {k: avg_us[k] * per_step[k] for k in per_step}
-        dom = max(flops, key=lambda k: share[k])   # the GEMM role with the largest share of a decode step
-        achieved = flops[dom] / avg_us[dom] * 1e-6  # TFLOP/s
-        kernel = {"qkv": "k_gemm<2,4,EPI_PACKED> 1536->4608 (QKV)", "fc1": "k_gemm<2,4,EPI_GELU,LN> 1536->6144 (FC1)",
-                  "fc2": "k_gemm<2,4,EPI_PACKED> 6144->1536 split-K (FC2)",
-                  "proj": "k_gemm<2,4,EPI_PACKED> 1536->1536 split-K (proj)",
-                  "head": "k_gemm<2,4,EPI_LOGITS,LN> 1536->16384 (head)"}[dom]
-        # HBM bytes per launch of that kernel from the committed PMC passes (profiles/pmc_fc1.json:
-        # separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction); null for other kernels
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_fc1.json")))
-            if dom == "fc1":
-                traffic = pmc["hbm_bytes_per_launch"]
-        except Exception:
-            pass
-        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TF, 4), "traffic": traffic, "kernel": kernel,
-                    "avg_us": round(avg_us[dom], 2), "launches_per_step": per_step[dom],
-                    "flop_per_launch": flops[dom],
-                    "share_of_decode_step": round(share[dom] / sum(share.values()), 3)}
-        gemm_tf = sum(flops[k] * per_step[k] for k in flops) / sum(share[k] for k in flops) * 1e-6
-        # decode attention against the HBM roofline: K and V rows of kv_avg cached tokens per (sequence, head)
-        attn_bytes = 2.0 * B * gcfg.n_embd * 4 * kv_avg
-        stage = {k: round(v, 2) for k, v in avg_us.items()}
-        step_ms_model = sum(share.values()) / 1e3
-        torch.cuda.synchronize()
-        t1 = time.perf_counter(); codes_t = model.sample(cond, GEN, True); torch.cuda.synchronize()
-        t2 = time.perf_counter(); im = model.codes_to_images(codes_t); torch.cuda.synchronize()
-        t3 = time.perf_counter(); c2 = model.images_to_codes(im); torch.cuda.synchronize()
-        t4 = time.perf_counter(); wm.detect_counts(c2); torch.cuda.synchronize()
-        t5 = time.perf_counter()
-        split = {"sample_s": round(t2 - t1, 4), "vq_decode_s": round(t3 - t2, 4), "vq_encode_s": round(t4 - t3, 4),
-                 "detect_s": round(t5 - t4, 5)}
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(gs, vs, gcfg, vcfg, wm, log)
+        S = codes.shape[1]
         out = {
-            "metric": "watermarked images/sec at 256x256 (16x16 tok), batch 64; detector p-value delta vs ref",
-            "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": METRIC, "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Taming cin_transformer (48L x 1536d x 24h, V=16384) + VQGAN f16/16384, 256x256, "
                                    "batch 64 per GPU, greenlist watermark delta=2 gamma=0.25 h=1 (linear/stratifiedrand), "
                                    "T=1 top-k 250 top-p 0.92; sample -> decode -> re-encode -> detect; random-init weights",
-                       "batch_per_gpu": B, "tokens_per_image": S, "parallelism": f"replicas x{world} (images sharded, no data-path collective)",
-                       "decode_loop": "eager" if args.no_graph else "hipGraph replay"},
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-            "stage_seconds_per_batch": split,
-            "decode_step_ms": round(split["sample_s"] / S * 1e3, 3),
-            "decode_kernel_avg_us": stage,
-            "decode_gemm_TFLOPs_all_roles": round(gemm_tf, 2),
-            "attention_hbm": {"achieved_GBs": round(attn_bytes / avg_us["attn"] * 1e-3, 1), "peak_GBs": PEAK_HBM_GBS,
-                              "kv_len": kv_avg},
+                       "batch_per_gpu": B, "tokens_per_image": S, "parallelism": f"replicas x{world} (images sharded, no data-path "
+                       "collective; codes / counts / p-values all-gathered once per step)", "decode_loop": "eager" if args.no_graph else "hipGraph replay",
+                       "backend": backend},
+            "gathered": {"codes": list(codes2_all.shape), "pvalues": int(pv.numel())},
             "detector": {"n_scored_mean": float(ns.float().mean()), "n_green_mean": float(ng.float().mean()),
                          "token_match_after_roundtrip": float((codes == codes2).float().mean())},
         }
+        if on_gpu and factory is default_engine:
+            out.update(gpu_analysis(model, wm, extra, cond, args, world, log))
+            # ~130 images/s/GPU fp32 roofline (0.33 s generation + 0.16 s decode/encode per 64 images)
+            out["end_to_end_frac_of_roofline"] = round(value / world / 130.0, 3)
+            out["parity"] = None if args.no_parity else parity_block(log)
+            out["cpu_baseline"] = None
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(extra["gs"], extra["vs"], extra["gcfg"], extra["vcfg"], wm, log)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

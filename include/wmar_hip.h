@@ -168,6 +168,10 @@ int wmar_gpt_generate(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_para
 #define WMAR_T_SAMPLE 8  /* fused watermark + sampling                         */
 #define WMAR_T_NCLASS 9
 int wmar_gpt_set_timing(wmar_gpt* g, int32_t enabled);
+/* Decode attention runs 1 / 2 / 4 waves per (sequence, head) while the cache holds <= one_wave_upto / <= two_waves_upto /
+ * more rows (one captured step graph per phase).  Defaults were measured at batch 64 on MI355X; a tuning entry point only --
+ * results do not depend on it beyond fp32 summation order across waves. */
+int wmar_gpt_set_attention_phases(wmar_gpt* g, int32_t one_wave_upto, int32_t two_waves_upto);
 /* Replays ONE role's kernel `iters` times back to back on `stream` (cycling through the layers, so
  * weights stream from HBM as in a real step) between two HIP events: *avg_us = average per launch,
  * launch boundary included.  kv_len = cached rows the attention role reads. */

@@ -35,9 +35,20 @@ def gpt():
     return GPTEngine(GCFG, synth.synth_gpt_state(GCFG, seed=9, logit_scale=10.0), max_batch=64)
 
 
-def test_gpt_1536_teacher_forced_256_positions(pv, gpt):
+@pytest.mark.parametrize("phases", [None, (112, 208), (0, 0)])
+def test_gpt_1536_teacher_forced_256_positions(pv, gpt, phases):
     """logits at positions 0,1,31,32,33,111,112,113,207,208,209,255 (every 64th logit) within 5e-4 of the reference's, the
-    arg-max token of all 64 rows at ALL 256 positions equal."""
+    arg-max token of all 64 rows at ALL 256 positions equal.  phases: the default (one attention wave per (sequence, head) at
+    every cache length), the 1 / 2 / 4-wave schedule switching at 112 / 208 rows, and four waves throughout."""
+    if phases is not None:
+        gpt.set_attention_phases(*phases)
+    try:
+        _teacher_forced(pv, gpt)
+    finally:
+        gpt.set_attention_phases(1 << 30, 1 << 30)
+
+
+def _teacher_forced(pv, gpt):
     seq = torch.from_numpy(pv["gpt_seq"].astype(np.int64)).cuda()
     want = {int(p): i for i, p in enumerate(pv["gpt_pos"])}
     worst, flips = 0.0, 0
@@ -58,14 +69,19 @@ def test_gpt_1536_teacher_forced_256_positions(pv, gpt):
     print(f"max |dlogit| over {len(want)} positions x 64 rows: {worst:.2e}; arg-max near-tie flips: {flips}")
 
 
-@pytest.mark.parametrize("graph", [True, False])
-def test_gpt_1536_watermarked_loop_256_steps(pv, kat, gpt, graph):
+@pytest.mark.parametrize("graph,phases", [(True, None), (False, None), (True, (112, 208))])
+def test_gpt_1536_watermarked_loop_256_steps(pv, kat, gpt, graph, phases):
     """sample_with_past, 256 steps, 4 rows, greenlist watermark + top-k 250 + top-p 0.92 on the reference's noise: the three
     captured step graphs (1 / 2 / 4 attention waves) reproduce the reference's token ids."""
     wm = _wm(kat["keys"]["taming"])
     torch.manual_seed(11)
     q = torch.stack([torch.empty(4, 16384).exponential_(1) for _ in range(256)]).cuda()
-    toks = gpt.generate(torch.from_numpy(pv["loop_cond"]).view(-1).cuda(), 256, q, 1.0, 250, 0.92, wm.wm_ctx(), use_graph=graph)
+    if phases is not None:
+        gpt.set_attention_phases(*phases)
+    try:
+        toks = gpt.generate(torch.from_numpy(pv["loop_cond"]).view(-1).cuda(), 256, q, 1.0, 250, 0.92, wm.wm_ctx(), use_graph=graph)
+    finally:
+        gpt.set_attention_phases(1 << 30, 1 << 30)
     ref = pv["loop_tokens"].astype(np.int64)
     got = toks.cpu().numpy()
     assert np.array_equal(got, ref), f"first mismatch per row: {[(int(np.argmax(g != r)) if (g != r).any() else -1) for g, r in zip(got, ref)]}"

@@ -46,6 +46,8 @@ def _deps(src: str):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
+    # development builds only (tuning scripts under scripts/): environment-variable knobs compiled in
+    dev = ["-DWMAR_DEV_KNOBS"] if os.environ.get("WMAR_DEV_KNOBS") else []
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     srcs = [(s, f) for s, f in SOURCES if os.path.exists(os.path.join(CSRC, s))]
@@ -54,7 +56,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(objdir, src + ".o")
         stale = force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src))
         if stale:
-            jobs.append((src, [hipcc] + COMMON + flags + ["-c", os.path.join(CSRC, src), "-o", obj]))
+            jobs.append((src, [hipcc] + COMMON + flags + dev + ["-c", os.path.join(CSRC, src), "-o", obj]))
 
     def run(job):
         src, cmd = job

@@ -69,8 +69,9 @@ struct wmar_cham {
 namespace {
 
 // workgroups of the stream-K GEMM: one per CU (measured: 256 -> 5.3 ms/step, 512 -> 5.9, 1024 -> 6.5 on the 7B model; the kernel
-// runs at one wave per SIMD, so more workgroups only add pieces and prologues); WMAR_CHAM_GRID overrides
+// runs at one wave per SIMD, so more workgroups only add pieces and prologues).  Dev builds (-DWMAR_DEV_KNOBS): WMAR_CHAM_GRID overrides.
 int cham_grid() {
+#ifdef WMAR_DEV_KNOBS
     static int g = 0;
     if (!g) {
         const char* e = getenv("WMAR_CHAM_GRID");
@@ -78,6 +79,9 @@ int cham_grid() {
         if (g < 1) g = 256;
     }
     return g;
+#else
+    return 256;
+#endif
 }
 
 SkInfo sk_for(int NT, int KB, bool whole_groups) {

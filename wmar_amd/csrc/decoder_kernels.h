@@ -17,7 +17,7 @@ __device__ __forceinline__ float4 ld_nt(const float4* p) {
 }
 
 constexpr int MAX_SLABS = 8;
-constexpr int QKV_SLABS_MAX = 4;   // the QKV projection is split at most 4 ways (1 by default)
+constexpr int QKV_SLABS_MAX = 8;   // the QKV projection arrives in at most 8 split-K pieces
 constexpr int STAT_CHUNKS_MAX = 64;   // n_embd <= 8192
 constexpr int GEMM_STAGE = 4;   // k-blocks (of 8) per register stage of the skinny GEMM
 
@@ -449,6 +449,266 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
 #endif
 }
 
+// ------------------------------------------------- residual fold + LN1 statistics + QKV projection in ONE launch
+// The QKV GEMM of layer l consumes the residual stream  x' = x + bias + sum_s slab[s]  of layer l-1's FC2 (k_resid_stats does
+// that fold as a launch of its own for the other consumers).  Here the fold happens while the operand is staged:
+//   * grid = G column groups (4 x 32 columns: one tile per wave, NO in-workgroup reduction) x S slices of K -- 36 x 7 = 252
+//     workgroups at n_embd 1536 instead of 144 column tiles that leave 112 CUs idle;
+//   * the 4 waves of a workgroup share the SAME K slice, so x' is formed ONCE per workgroup, chunk by chunk (4 k-blocks: one
+//     per wave), written to LDS and read back by all four as the MFMA B operand: the (1 + S_in)-fold read of the fold costs
+//     ~14 KiB per k-block against 4 KiB of weights, inside the CU's L1 fill rate;
+//   * column group 0 also writes x' to the OTHER residual buffer (the other groups still read the old one) and the fp64 row
+//     sums of its K slice: S partial statistics per row for the attention prologue's LayerNorm algebra;
+//   * every wave stores its accumulators as one of S split-K pieces, which the attention prologue sums in slice order.
+// Weights: a wave walks its own column tile, loads issued two chunks (2 x 2048 MFMA cycles) ahead of use.
+constexpr int QX_CK = 4;      // k-blocks per chunk (one staged by each wave)
+
+struct QkvxArgs {
+    const float4* Wp;          // [NT][KB][64] gamma-folded QKV weights
+    const float4* x_in;        // packed [KB][MT][64]: residual stream before the fold
+    float4* x_out;             // residual stream after the fold (a different buffer)
+    const float4* slabs;       // [S_IN][KB*MT*64]: split-K partial sums of the previous FC2
+    long long slab_stride;     // float4 units
+    int n_hi;                  // > 0: slab S_IN-1 exists only for column tiles < n_hi (see ResidArgs)
+    const float* bias;         // [K] bias of the previous FC2 (S_IN > 0)
+    double* stats;             // [S][Mpad][2]: (sum, sum of squares) of x' over K slice s
+    float4* out;               // [S][3D/8][MT][64] split-K pieces of the projection
+    long long out_stride;      // float4 units
+    int KB, NT, S, cap;        // cap: workgroup slots per XCD (grid = 8 * cap)
+    unsigned long long* trace; // dev only (WMAR_QX_TRACE): 4 timestamps per wave
+};
+
+// MTW = row tiles (all of them: MT == MTW); S_IN = slabs folded into x (0: x is used as it is, layer 0).  Both are template
+// parameters so that EVERY load is unconditional and counted at compile time: hipcc's s_waitcnt placement then waits for exactly
+// the operands a step needs.  Out-of-range k-blocks of a short last chunk re-read an in-bounds block instead of branching.
+//
+// Eight waves, two roles (one wave of each role per SIMD):
+//   * waves 4..7 STAGE: wave 4+i forms k-block i of every chunk -- x + (bias + slabs in slab order), the arithmetic of
+//     k_resid_stats -- and writes it to LDS; its loads run two chunks ahead of the chunk it finishes (two register sets), so
+//     the L2 / fabric latency of the slabs never reaches the matrix pipe.  In column group 0 they also publish x' and the
+//     fp64 row sums of their slice.
+//   * waves 0..3 MULTIPLY: wave i owns column tile 4g+i; weights stream through a 4-chunk register ring (requested three
+//     chunks = ~6000 cycles ahead of use), the B operand comes from LDS.  The fragments of chunk c+1 are read under the last 8
+//     MFMAs of chunk c, so the MFMA stream has no bubbles at chunk boundaries.
+// One barrier per chunk: barrier(c) = "chunk c+1 is in LDS" and "chunk c has been read" (the reads of a chunk happen at its start,
+// so the multiplying waves reach the barrier three quarters into the chunk and the stagers have a whole chunk of time).
+template <int MTW, int S_IN>
+__global__ __launch_bounds__(512) void k_qkvx(QkvxArgs a) {
+    __shared__ __attribute__((aligned(16))) float4 xs[2][QX_CK][MTW][64];
+    __shared__ double red[4][MTW][32][2];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5;
+    // workgroups with the same K slice share an XCD (block b runs on XCD b % 8): the slice of x and of the slabs is then
+    // fetched into that XCD's L2 once.  Placement only changes speed, never results.
+    const int G = a.NT >> 2;
+    const int j = (int)(blockIdx.x & 7) * a.cap + (int)(blockIdx.x >> 3);
+    if (j >= G * a.S) return;
+    const int s = j / G, g = j - s * G;
+    const int kb0 = (int)((unsigned)s * (unsigned)a.KB / (unsigned)a.S);
+    const int kb1 = (int)((unsigned)(s + 1) * (unsigned)a.KB / (unsigned)a.S);
+    const int nkb = kb1 - kb0, nch = (nkb + QX_CK - 1) / QX_CK;
+    const bool keeper = g == 0;          // this workgroup also publishes x' and the row sums of its slice
+
+    if (w >= 4) {
+        // ------------------------------------------------------------------------------------------ staging waves
+        const int sw = w - 4;
+        double sum[MTW], sq[MTW];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) { sum[i] = 0.0; sq[i] = 0.0; }
+        float4 xvA[MTW], bbA, slA[S_IN > 0 ? S_IN : 1][MTW];
+        float4 xvB[MTW], bbB, slB[S_IN > 0 ? S_IN : 1][MTW];
+        int skbA = 0, skbB = 0;
+#define WMAR_QX_ISSUE(XV, BB, SL, SKB, C)                                                              \
+    {                                                                                                   \
+        SKB = kb0 + (C) * QX_CK + sw;                                                                   \
+        const int kk = SKB < kb1 ? SKB : kb1 - 1;                                                       \
+        const long long idx = (long long)kk * MTW * 64 + lane;                                          \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i) XV[i] = a.x_in[idx + i * 64];                   \
+        if (S_IN > 0) {                                                                                 \
+            BB = *(const float4*)(a.bias + kk * 8 + 4 * half);                                          \
+            _Pragma("unroll") for (int si = 0; si < S_IN; ++si)                                         \
+                _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                         \
+                    SL[si][i] = a.slabs[(long long)si * a.slab_stride + idx + i * 64];                  \
+        }                                                                                               \
+    }
+#define WMAR_QX_FINISH(XV, BB, SL, SKB, BUF)                                                           \
+    if (SKB < kb1) {                                                                                    \
+        const bool short_tile = a.n_hi > 0 && (SKB >> 2) >= a.n_hi;                                     \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i) {                                               \
+            float4 r = XV[i];                                                                           \
+            if (S_IN > 0) {                                                                             \
+                float4 t = SL[0][i];                                                                    \
+                _Pragma("unroll") for (int si = 1; si < S_IN; ++si)                                     \
+                    if (!(si == S_IN - 1 && short_tile)) {                                              \
+                        t.x += SL[si][i].x; t.y += SL[si][i].y; t.z += SL[si][i].z; t.w += SL[si][i].w; \
+                    }                                                                                   \
+                r = make_float4(r.x + (BB.x + t.x), r.y + (BB.y + t.y), r.z + (BB.z + t.z), r.w + (BB.w + t.w)); \
+            }                                                                                           \
+            xs[BUF][sw][i][lane] = r;                                                                   \
+            if (keeper) {                                                                               \
+                a.x_out[((long long)SKB * MTW + i) * 64 + lane] = r;                                    \
+                sum[i] += (double)r.x + (double)r.y + (double)r.z + (double)r.w;                        \
+                sq[i] += (double)r.x * r.x + (double)r.y * r.y + (double)r.z * r.z + (double)r.w * r.w; \
+            }                                                                                           \
+        }                                                                                               \
+    }
+        WMAR_QX_ISSUE(xvA, bbA, slA, skbA, 0)
+        WMAR_QX_ISSUE(xvB, bbB, slB, skbB, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        // sched_barrier(0) after every block: hipcc otherwise sinks the loads of a set down to the FINISH that consumes them
+        // (it minimises register lifetimes), which would expose one full memory round trip per chunk
+        WMAR_QX_FINISH(xvA, bbA, slA, skbA, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        WMAR_QX_ISSUE(xvA, bbA, slA, skbA, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                   // barrier(-1): chunk 0 is in LDS
+        for (int c = 0; c + 1 < nch; c += 2) {
+            WMAR_QX_FINISH(xvB, bbB, slB, skbB, 1)         // chunk c+1
+            __builtin_amdgcn_sched_barrier(0);
+            WMAR_QX_ISSUE(xvB, bbB, slB, skbB, c + 3)
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                               // barrier(c)
+            if (c + 2 >= nch) break;
+            WMAR_QX_FINISH(xvA, bbA, slA, skbA, 0)         // chunk c+2
+            __builtin_amdgcn_sched_barrier(0);
+            WMAR_QX_ISSUE(xvA, bbA, slA, skbA, c + 4)
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                               // barrier(c+1)
+        }
+#undef WMAR_QX_ISSUE
+#undef WMAR_QX_FINISH
+        if (keeper) {
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+                sum[i] += __shfl_xor(sum[i], 32);
+                sq[i] += __shfl_xor(sq[i], 32);
+                if (lane < 32) { red[sw][i][lane][0] = sum[i]; red[sw][i][lane][1] = sq[i]; }
+            }
+            __syncthreads();                               // the multiplying waves meet it after their stores
+            const int t = threadIdx.x - 256;
+            if (t < 32 * MTW) {
+                const int i = t >> 5, r = t & 31;
+                double ts = 0, tss = 0;
+                for (int ww = 0; ww < 4; ++ww) { ts += red[ww][i][r][0]; tss += red[ww][i][r][1]; }
+                double* o = a.stats + ((long long)s * (MTW * 32) + i * 32 + r) * 2;
+                o[0] = ts; o[1] = tss;
+            }
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------------------------------ multiplying waves
+    const int nt = g * 4 + w;
+    f32x16 acc[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const float4* Wp = a.Wp + ((long long)nt * a.KB + kb0) * 64 + lane;
+    float4 w0[QX_CK], w1[QX_CK], w2[QX_CK], w3[QX_CK];
+    float4 xfA[QX_CK][MTW], xfB[QX_CK][MTW];
+#define WMAR_QX_W(WBUF, C)                                                                             \
+    _Pragma("unroll") for (int u = 0; u < QX_CK; ++u) {                                                 \
+        const int kl = (C) * QX_CK + u;                                                                 \
+        WBUF[u] = ld_nt(Wp + (long long)(kl < nkb ? kl : nkb - 1) * 64);                                \
+    }
+#define WMAR_QX_READ(XF, BUF)                                                                          \
+    _Pragma("unroll") for (int u = 0; u < QX_CK; ++u)                                                   \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i) XF[u][i] = xs[BUF][u][i][lane];
+#define WMAR_QX_MMA(WBUF, XF, C, U0, U1)                                                               \
+    _Pragma("unroll") for (int u = U0; u < U1; ++u)                                                     \
+        if ((C) * QX_CK + u < nkb) {                                                                    \
+            const float4 wv = WBUF[u];                                                                  \
+            _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                             \
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, XF[u][i].x, acc[i], 0, 0, 0);       \
+            _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                             \
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, XF[u][i].y, acc[i], 0, 0, 0);       \
+            _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                             \
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, XF[u][i].z, acc[i], 0, 0, 0);       \
+            _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                             \
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, XF[u][i].w, acc[i], 0, 0, 0);       \
+        }
+// one chunk: request the weights three chunks ahead, multiply three k-blocks, pass the chunk barrier and read the next chunk's
+// fragments, multiply the last k-block
+#define WMAR_QX_STEP(C, WCUR, WFAR, XCUR, XNEXT, BUFNEXT)                                              \
+    WMAR_QX_W(WFAR, (C) + 3)                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    WMAR_QX_MMA(WCUR, XCUR, C, 0, QX_CK - 1)                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if ((C) + 1 < nch) {                                                                                \
+        __syncthreads();                                                                                \
+        WMAR_QX_READ(XNEXT, BUFNEXT)                                                                    \
+    }                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    WMAR_QX_MMA(WCUR, XCUR, C, QX_CK - 1, QX_CK)                                                        \
+    __builtin_amdgcn_sched_barrier(0);
+
+#ifdef WMAR_QX_TRACE
+    const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
+#endif
+    WMAR_QX_W(w0, 0)
+    WMAR_QX_W(w1, 1)
+    WMAR_QX_W(w2, 2)
+    __syncthreads();                                       // barrier(-1)
+#ifdef WMAR_QX_TRACE
+    const unsigned long long tr1 = __builtin_amdgcn_s_memtime();
+#endif
+    WMAR_QX_READ(xfA, 0)
+    for (int c = 0; c < nch; c += 4) {
+        WMAR_QX_STEP(c, w0, w3, xfA, xfB, 1)
+        if (c + 1 >= nch) break;
+        WMAR_QX_STEP(c + 1, w1, w0, xfB, xfA, 0)
+        if (c + 2 >= nch) break;
+        WMAR_QX_STEP(c + 2, w2, w1, xfA, xfB, 1)
+        if (c + 3 >= nch) break;
+        WMAR_QX_STEP(c + 3, w3, w2, xfB, xfA, 0)
+    }
+#undef WMAR_QX_W
+#undef WMAR_QX_READ
+#undef WMAR_QX_MMA
+#undef WMAR_QX_STEP
+
+#ifdef WMAR_QX_TRACE
+    asm volatile("s_nop 0" ::: "memory");
+    const unsigned long long tr2 = __builtin_amdgcn_s_memtime();
+#endif
+    // one split-K piece per wave, straight from the accumulators (already the packed layout of the consumer)
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+            a.out[(long long)s * a.out_stride + ((long long)(nt * 4 + q4) * MTW + i) * 64 + lane] =
+                make_float4(acc[i][q4 * 4 + 0], acc[i][q4 * 4 + 1], acc[i][q4 * 4 + 2], acc[i][q4 * 4 + 3]);
+    if (keeper) __syncthreads();
+#ifdef WMAR_QX_TRACE
+    if (a.trace && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* t = a.trace + ((long long)j * 4 + w) * 4;
+        t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = __builtin_amdgcn_s_memtime();
+    }
+#endif
+}
+
+template <int MTW>
+static int launch_qkvx_mt(const QkvxArgs& q, int S_in, hipStream_t st) {
+    const dim3 grid((unsigned)(8 * q.cap));
+    switch (S_in) {
+#define WMAR_QX_CASE(N) case N: hipLaunchKernelGGL((k_qkvx<MTW, N>), grid, dim3(512), 0, st, q); break;
+        WMAR_QX_CASE(0) WMAR_QX_CASE(1) WMAR_QX_CASE(2) WMAR_QX_CASE(3) WMAR_QX_CASE(4)
+        WMAR_QX_CASE(5) WMAR_QX_CASE(6) WMAR_QX_CASE(7) WMAR_QX_CASE(8)
+#undef WMAR_QX_CASE
+        default: set_error("qkvx: bad slab count %d", S_in); return WMAR_EINVAL;
+    }
+    return launch_status("k_qkvx");
+}
+static int launch_qkvx(const QkvxArgs& q, int MT, int S_in, hipStream_t st) {
+    if (MT == 1) return launch_qkvx_mt<1>(q, S_in, st);
+    if (MT == 2) return launch_qkvx_mt<2>(q, S_in, st);
+    set_error("qkvx: %d row tiles unsupported", MT);
+    return WMAR_EINVAL;
+}
+
 // --------------------------------------------------------------------- decode attention
 // One wave per (sequence, head).  K/V rows are hd floats; LPR = hd/4 lanes cover a row with
 // float4s and RPI = 64/LPR rows are read per wave-wide load (1 KiB, coalesced).
@@ -471,14 +731,14 @@ struct AttnArgs {
     const int* pos_dev;
     int D, H, Tmax, MT;
     float scale;
-    int dbg;                   // dev ablation (WMAR_ATT_DBG): 2 = skip K/V streaming
+    int dbg;                   // dev builds only (-DWMAR_DEV_KNOBS, WMAR_ATT_DBG): 2 = skip K/V streaming
 };
 
 // One workgroup of NWA waves per (sequence, head).  The cached rows are cut into chunks of
 // CH 1-KiB loads (CH*RPI rows); wave w takes chunks w, w+NWA, ...  and keeps a running
 // (max, sum, weighted V sum) in registers -- K and V of a chunk are requested together, the next
 // chunk is in flight while the current one is reduced.  The NWA partial results meet in LDS.
-template <int HD, int NWA>
+template <int HD, int NWA, bool PF2 = false>
 __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
     // LPRA lanes (one float4 each) cover a cache row; rows are laid on LPR = next power of two lanes so
     // that the row reductions are xor-shuffles (hd = 80: 20 of 32 lanes active, 2 rows per load).
@@ -499,7 +759,11 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
     const int sub = lane_on ? subr : 0;
     float* Kc = a.kcache + ((long long)b * a.H + h) * a.Tmax * HD + sub * 4;
     float* Vc = a.vcache + ((long long)b * a.H + h) * a.Tmax * HD + sub * 4;
+#ifdef WMAR_DEV_KNOBS
     const int nchunk = (a.dbg & 2) ? 0 : (T + ROWS - 1) / ROWS;
+#else
+    const int nchunk = (T + ROWS - 1) / ROWS;
+#endif
 
     // rows past T-1 are clamped to T-1 and replaced from registers / masked below
 #define WMAR_ATT_LOAD(KB, VB, C0)                                                        \
@@ -510,7 +774,10 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
     }
     float4 kA[CH], vA[CH], kB[CH], vB[CH];
     float4 q, knew, vnew;
-    if (w < nchunk) { WMAR_ATT_LOAD(kA, vA, w) }   // in flight while q/k/v are finished
+    // PF2: the wave's first TWO chunks are requested before the prologue (32 KiB in flight per wave: with 1 / 2 / 4 waves the
+    // whole cache up to 64 / 128 / 256 rows streams while q/k/v are finished); otherwise one, the second from inside the loop
+    if (w < nchunk) { WMAR_ATT_LOAD(kA, vA, w) }
+    if (PF2 && w + NWA < nchunk) { WMAR_ATT_LOAD(kB, vB, w + NWA) }
     __builtin_amdgcn_sched_barrier(0);
     // ---- wave 0 finishes this head's q, k, v for the new token from the QKV slab(s) and hands
     // them to the other waves through LDS.  Loads are issued by as few lanes as possible: a
@@ -523,15 +790,22 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
         double sm = 0, sq = 0;
         double2 st0 = make_double2(0.0, 0.0);
         if (a.mode == 0 && lane < a.n_chunks) st0 = *(const double2*)(a.stats + ((long long)lane * Mpad + b) * 2);
-        float4 sl[3][QKV_SLABS_MAX], cc[3], bb[3];
-        if (rsel == 0) {
+        // The S split-K pieces of this head's 3 x hd columns are spread over the wave's RPI row groups (piece p is fetched by
+        // group p % RPI), so that a lane holds at most PMAX pieces: all loads are still in flight together, without 3 x 8
+        // float4 registers per lane (the kernel's occupancy is set by its registers).  The partial sums meet in a fixed
+        // xor-butterfly over the groups: the summation order depends on S only.
+        constexpr int PMAX = (QKV_SLABS_MAX + RPI - 1) / RPI;
+        float4 sl[3][PMAX], cc[3], bb[3];
 #pragma unroll
-            for (int which = 0; which < 3; ++which) {
-                const int n = which * a.D + h * HD + sub * 4;          // first of this lane's 4 columns
-                const long long idx = ((long long)(n >> 3) * a.MT + mt) * 64 + (b & 31) + 32 * ((n >> 2) & 1);
+        for (int which = 0; which < 3; ++which) {
+            const int n = which * a.D + h * HD + sub * 4;          // first of this lane's 4 columns
+            const long long idx = ((long long)(n >> 3) * a.MT + mt) * 64 + (b & 31) + 32 * ((n >> 2) & 1);
 #pragma unroll
-                for (int sidx = 0; sidx < QKV_SLABS_MAX; ++sidx)
-                    sl[which][sidx] = a.qkv_slabs[(long long)min(sidx, a.S - 1) * a.slab_stride + idx];
+            for (int pi = 0; pi < PMAX; ++pi) {
+                const int pc = rsel + pi * RPI;
+                sl[which][pi] = pc < a.S ? a.qkv_slabs[(long long)pc * a.slab_stride + idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (rsel == 0) {
                 cc[which] = a.mode == 0 ? *(const float4*)(a.c1 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                 bb[which] = *(const float4*)(a.bias + n);
             }
@@ -547,17 +821,28 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
         const double mean = sm * invK;
         const float mu = (float)mean;
         const float rstd = rsqrtf((float)(sq * invK - mean * mean) + 1e-5f);
+        float4 accs[3];
+#pragma unroll
+        for (int which = 0; which < 3; ++which) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int pi = 0; pi < PMAX; ++pi)
+                if (rsel + pi * RPI < a.S) {
+                    acc.x += sl[which][pi].x; acc.y += sl[which][pi].y;
+                    acc.z += sl[which][pi].z; acc.w += sl[which][pi].w;
+                }
+#pragma unroll
+            for (int o = LPR; o < 64; o <<= 1) {
+                acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o);
+                acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
+            }
+            accs[which] = acc;
+        }
         if (rsel == 0) {
             float4 r[3];
 #pragma unroll
             for (int which = 0; which < 3; ++which) {
-                float4 acc = sl[which][0];
-#pragma unroll
-                for (int sidx = 1; sidx < QKV_SLABS_MAX; ++sidx)
-                    if (sidx < a.S) {
-                        acc.x += sl[which][sidx].x; acc.y += sl[which][sidx].y;
-                        acc.z += sl[which][sidx].z; acc.w += sl[which][sidx].w;
-                    }
+                const float4 acc = accs[which];
                 if (a.mode == 0) {
                     r[which] = make_float4(rstd * (acc.x - mu * cc[which].x) + bb[which].x,
                                            rstd * (acc.y - mu * cc[which].y) + bb[which].y,
@@ -629,13 +914,15 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
         m = mn;                                                                          \
     }
     for (int c = w; c < nchunk; c += 2 * NWA) {
-        if (c + NWA < nchunk) { WMAR_ATT_LOAD(kB, vB, c + NWA) }
+        if (!PF2 && c == w && c + NWA < nchunk) { WMAR_ATT_LOAD(kB, vB, c + NWA) }
         __builtin_amdgcn_sched_barrier(0);
         WMAR_ATT_CHUNK(kA, vA, c)
         __builtin_amdgcn_sched_barrier(0);
         if (c + 2 * NWA < nchunk) { WMAR_ATT_LOAD(kA, vA, c + 2 * NWA) }
         __builtin_amdgcn_sched_barrier(0);
         if (c + NWA < nchunk) { WMAR_ATT_CHUNK(kB, vB, c + NWA) }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 3 * NWA < nchunk) { WMAR_ATT_LOAD(kB, vB, c + 3 * NWA) }
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef WMAR_ATT_LOAD

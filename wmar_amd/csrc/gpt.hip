@@ -41,9 +41,10 @@ struct wmar_gpt {
     float *tok_emb = nullptr, *pos_emb = nullptr, *bhead = nullptr, *chead = nullptr;
     float4* whead = nullptr;
     // workspaces
-    float4 *x = nullptr, *y = nullptr, *hbuf = nullptr, *slabs = nullptr, *qkv_slabs = nullptr;
+    float4 *x = nullptr, *x2 = nullptr, *y = nullptr, *hbuf = nullptr, *slabs = nullptr, *qkv_slabs = nullptr;
     float* qbuf = nullptr;
     double* stats = nullptr;
+    double* stats_q = nullptr;   // [QKV_SLABS_MAX][Mpad][2]: LN1 row sums per K slice, written by k_qkvx
     float *kcache = nullptr, *vcache = nullptr;
     float *logits = nullptr, *scratch = nullptr;
     long long* past = nullptr;  // [Bmax][Tmax+1]
@@ -68,7 +69,11 @@ struct wmar_gpt {
         }
     }
     // phase of the step that attends to `kv` cached rows (including the new one)
-    static int att_phase(int kv) { return kv <= 112 ? 0 : (kv <= 208 ? 1 : 2); }
+    // Measured at batch 64 with the QKV projection arriving in 7 split-K pieces (round 2): one wave per (sequence, head) is the
+    // fastest variant at every cache length up to 256 (the prologue that sums the pieces runs in wave 0 while the others
+    // wait), so by default every step is phase 0.  wmar_gpt_set_attention_phases moves the thresholds.
+    int att_t1 = 1 << 30, att_t2 = 1 << 30;
+    int att_phase(int kv) const { return kv <= att_t1 ? 0 : (kv <= att_t2 ? 1 : 2); }
     static int phase_waves(int ph) { return ph == 0 ? 1 : (ph == 1 ? 2 : 4); }
     int timing = 0;
     int force_s[3] = {0, 0, 0};   // tuning knobs: WMAR_S_QKV / WMAR_S_PROJ / WMAR_S_FC2
@@ -153,6 +158,9 @@ struct StepPlan {
     ResidArgs r{};
     int S_qkv = 1, S_proj = 1, S_fc2 = 1;
     int fc2_hi = 0;      // FC2: the first fc2_hi column tiles take S_fc2 + 1 K slices so that exactly 256 workgroups exist
+    // fused residual fold + QKV projection (k_qkvx): column groups x K slices; 0 = not applicable to this shape (k_gemm path)
+    int S_qx = 0;
+    float4* xcur = nullptr;   // residual stream buffer the next launch reads (the fused fold ping-pongs between x and x2)
 
     StepPlan(wmar_gpt* g_, int64_t B_, const StepIO& io_, hipStream_t st_) : g(g_), B(B_), io(io_), st(st_) {
         MT = mt_for(B); D = g->D; KBD = D / 8; KBF = 4 * D / 8; nch = stat_chunks(KBD);
@@ -161,6 +169,7 @@ struct StepPlan {
         r.tok_emb = g->tok_emb; r.pos_emb = g->pos_emb; r.tok = io.tok; r.tok_stride = io.tok_stride;
         r.tok_use_pos = io.tok_use_pos; r.pos_dev = g->pos_dev; r.B = (int)B; r.K = D;
         r.slabs = g->slabs; r.slab_stride = act;
+        xcur = g->x;
         // split factors (fixed per shape so that a role can be replayed on its own)
         S_qkv = g->force_s[0] > 0 ? (g->force_s[0] > QKV_SLABS_MAX ? QKV_SLABS_MAX : g->force_s[0]) : 1;
         S_proj = g->force_s[1] > 0 ? g->force_s[1] : split_for(D / 32, KBD);
@@ -172,6 +181,16 @@ struct StepPlan {
             const int Slo = 256 / NTd;
             if (Slo >= 2 && Slo < MAX_SLABS && NTd * Slo <= 256) { S_fc2 = Slo; fc2_hi = 256 - NTd * Slo; if (fc2_hi >= NTd) fc2_hi = 0; }
         }
+        // k_qkvx: 128-column groups x S slices of K, as close to one workgroup per CU as the shape allows.  Shapes it does not
+        // fit (n_embd not a multiple of 128, more than 64 rows) keep the k_gemm path.
+        const int NTq = 3 * D / 32;
+        if (g->force_s[0] <= 0 && NTq % 4 == 0 && MT <= 2 && S_fc2 + (fc2_hi > 0 ? 1 : 0) <= MAX_SLABS) {
+            const int G = NTq / 4;
+            int S = 256 / G;
+            if (S > QKV_SLABS_MAX) S = QKV_SLABS_MAX;
+            if (S > KBD / QX_CK) S = KBD / QX_CK;
+            if (S >= 1) S_qx = S;
+        }
     }
     int split_for(int NT, int KB) const { return pick_split(MT % 2 == 0 ? NT * (MT / 2) : NT * MT, KB, 4); }
     GemmArgs base() const {
@@ -181,6 +200,7 @@ struct StepPlan {
         return a;
     }
     int embed() {
+        r.x = xcur;
         g->span_begin(WMAR_T_EMBED, st);
         hipLaunchKernelGGL((k_resid_stats<true, 0>), dim3(nch * MT), dim3(256), 0, st, r);
         g->span_end(st);
@@ -188,6 +208,7 @@ struct StepPlan {
     }
     // x += bias + sum of the S partial slabs; LN statistics of the new rows
     int resid(const float* bias, int S, int n_hi = 0) {
+        r.x = xcur;
         r.S = S + (n_hi > 0 ? 1 : 0); r.bias = bias; r.n_hi = n_hi;
         g->span_begin(WMAR_T_RESID, st);
         int rc = launch_resid(r, nch * MT, st);
@@ -198,10 +219,29 @@ struct StepPlan {
     // finished per (sequence, head) in the attention kernel's prologue.  Measured: one slab (no K
     // split across workgroups) beats every split for this shape -- more, thinner workgroups per CU
     // contend for the same L1 fill path.
+    // Layer l's QKV projection with the residual fold of layer l-1's FC2 (bias `prev_bias`, slabs in g->slabs) staged on the
+    // fly; prev_bias == nullptr: nothing to fold (layer 0 reads the embedding).  Switches xcur to the other buffer.
+    int qkvx(int l, const float* prev_bias) {
+        QkvxArgs q{};
+        const LayerW& w = g->layers[l];
+        float4* xout = (xcur == g->x) ? g->x2 : g->x;
+        q.Wp = w.wqkv; q.x_in = xcur; q.x_out = xout;
+        q.slabs = g->slabs; q.slab_stride = act;
+        const int S_in = prev_bias ? S_fc2 + (fc2_hi > 0 ? 1 : 0) : 0;
+        q.n_hi = prev_bias ? fc2_hi : 0; q.bias = prev_bias;
+        q.stats = g->stats_q; q.out = g->qkv_slabs; q.out_stride = 3 * act;
+        q.KB = KBD; q.NT = 3 * D / 32; q.S = S_qx;
+        q.cap = ((q.NT / 4) * q.S + 7) / 8;
+        g->span_begin(WMAR_T_QKV, st);
+        const int rc = launch_qkvx(q, MT, S_in, st);
+        g->span_end(st);
+        xcur = xout;
+        return rc;
+    }
     int qkv(int l) {
         GemmArgs a = base();
         const LayerW& w = g->layers[l];
-        a.Wp = w.wqkv; a.Xp = g->x; a.KB = KBD; a.NT = 3 * D / 32;
+        a.Wp = w.wqkv; a.Xp = xcur; a.KB = KBD; a.NT = 3 * D / 32;
         a.out_packed = g->qkv_slabs; a.slab_stride = 3 * act;
         int S = 1;
         g->span_begin(WMAR_T_QKV, st);
@@ -213,22 +253,29 @@ struct StepPlan {
         const LayerW& w = g->layers[l];
         const long long lstride = (long long)g->Bmax * g->H * g->Tmax * g->hd;
         AttnArgs t{};
-        t.qkv_slabs = g->qkv_slabs; t.slab_stride = 3 * act; t.S = S_qkv; t.stats = g->stats; t.n_chunks = nch; t.K = D;
+        t.qkv_slabs = g->qkv_slabs; t.slab_stride = 3 * act; t.K = D;
+        if (S_qx > 0) { t.S = S_qx; t.stats = g->stats_q; t.n_chunks = S_qx; }
+        else { t.S = S_qkv; t.stats = g->stats; t.n_chunks = nch; }
         t.c1 = w.cqkv; t.bias = w.bqkv;
         t.kcache = g->kcache + l * lstride; t.vcache = g->vcache + l * lstride; t.y = g->y; t.pos_dev = g->pos_dev;
         t.D = D; t.H = g->H; t.Tmax = g->Tmax; t.MT = MT; t.scale = 1.0f / sqrtf((float)g->hd);
+        int nwa = g->att_nw;   // chosen per phase by the caller (generate / profile_role)
+#ifdef WMAR_DEV_KNOBS
         { const char* e = getenv("WMAR_ATT_DBG"); t.dbg = e ? atoi(e) : 0; }
-        int nwa = g->att_nw;   // chosen per phase by the caller (generate / profile_role); WMAR_ATT_NW pins it
         { const char* e = getenv("WMAR_ATT_NW"); if (e) nwa = atoi(e); }
+#endif
         const dim3 grid((unsigned)(B * g->H));
         g->span_begin(WMAR_T_ATTN, st);
-#define WMAR_ATT_LAUNCH(HDV)                                                                              \
-        if (nwa == 1) hipLaunchKernelGGL((k_attn_decode<HDV, 1>), grid, dim3(64), 0, st, t);                   \
-        else if (nwa == 2) hipLaunchKernelGGL((k_attn_decode<HDV, 2>), grid, dim3(128), 0, st, t);             \
-        else hipLaunchKernelGGL((k_attn_decode<HDV, 4>), grid, dim3(256), 0, st, t);
+#define WMAR_ATT_LAUNCH2(HDV, PF)                                                                         \
+        if (nwa == 1) hipLaunchKernelGGL((k_attn_decode<HDV, 1, PF>), grid, dim3(64), 0, st, t);               \
+        else if (nwa == 2) hipLaunchKernelGGL((k_attn_decode<HDV, 2, PF>), grid, dim3(128), 0, st, t);         \
+        else hipLaunchKernelGGL((k_attn_decode<HDV, 4, PF>), grid, dim3(256), 0, st, t);
+#define WMAR_ATT_LAUNCH(HDV) if (pf2) { WMAR_ATT_LAUNCH2(HDV, true) } else { WMAR_ATT_LAUNCH2(HDV, false) }
+        const bool pf2 = false;    // measured equal within noise at 1 wave per (sequence, head); kept for the 2- and 4-wave variants
         if (g->hd == 64) { WMAR_ATT_LAUNCH(64) }
         else if (g->hd == 32) { WMAR_ATT_LAUNCH(32) }
         else { WMAR_ATT_LAUNCH(128) }
+#undef WMAR_ATT_LAUNCH2
 #undef WMAR_ATT_LAUNCH
         g->span_end(st);
         return launch_status("k_attn_decode");
@@ -248,7 +295,7 @@ struct StepPlan {
     int fc1(int l) {
         GemmArgs f = base();
         const LayerW& w = g->layers[l];
-        f.Wp = w.wfc1; f.Xp = g->x; f.bias = w.bfc1; f.c1 = w.cfc1; f.KB = KBD; f.NT = 4 * D / 32;
+        f.Wp = w.wfc1; f.Xp = xcur; f.bias = w.bfc1; f.c1 = w.cfc1; f.KB = KBD; f.NT = 4 * D / 32;
         f.out_packed = g->hbuf; f.slab_stride = 0;
         g->span_begin(WMAR_T_FC1, st);
         int rc = gemm_dispatch<EPI_GELU, true>(f, false, st);
@@ -268,7 +315,7 @@ struct StepPlan {
     // ln_f -> vocabulary head
     int head() {
         GemmArgs h = base();
-        h.Wp = g->whead; h.Xp = g->x; h.KB = KBD; h.NT = g->V / 32;
+        h.Wp = g->whead; h.Xp = xcur; h.KB = KBD; h.NT = g->V / 32;
         h.bias = g->bhead; h.c1 = g->chead; h.logits = io.logits; h.V = g->V;
         g->span_begin(WMAR_T_HEAD, st);
         // at most one workgroup per CU per launch: two workgroups on a CU share its MFMA pipes and L1 fill path, so 512 column
@@ -296,8 +343,12 @@ int enqueue_step(wmar_gpt* g, int64_t B, const StepIO& io, hipStream_t st) {
     int rc;
     if ((rc = p.embed())) return rc;
     for (int l = 0; l < g->L; ++l) {
-        if (l > 0 && (rc = p.resid(g->layers[l - 1].bfc2, p.S_fc2, p.fc2_hi))) return rc;
-        if ((rc = p.qkv(l))) return rc;
+        if (p.S_qx > 0) {
+            if ((rc = p.qkvx(l, l > 0 ? g->layers[l - 1].bfc2 : nullptr))) return rc;
+        } else {
+            if (l > 0 && (rc = p.resid(g->layers[l - 1].bfc2, p.S_fc2, p.fc2_hi))) return rc;
+            if ((rc = p.qkv(l))) return rc;
+        }
         if ((rc = p.attn(l))) return rc;
         if ((rc = p.proj(l))) return rc;
         if ((rc = p.resid(g->layers[l].bproj, p.S_proj))) return rc;
@@ -327,6 +378,7 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
     auto* g = new wmar_gpt();
     g->cfg = *cfg; g->D = D; g->H = H; g->hd = hd; g->V = V; g->L = L; g->Tmax = cfg->block_size; g->Bmax = cfg->max_batch;
     g->MTmax = mt_for(cfg->max_batch);
+#ifdef WMAR_DEV_KNOBS
     {
         const char* names_s[3] = {"WMAR_S_QKV", "WMAR_S_PROJ", "WMAR_S_FC2"};
         for (int i = 0; i < 3; ++i) {
@@ -334,6 +386,7 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
             if (e) g->force_s[i] = atoi(e) > MAX_SLABS ? MAX_SLABS : atoi(e);
         }
     }
+#endif
     int rc = WMAR_OK;
     auto need = [&](const std::string& k) -> const float* {
         const float* p = tm.get(k);
@@ -393,12 +446,14 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
     }
     const size_t Mpad = (size_t)g->MTmax * 32;
     TRY(g->alloc(&g->x, Mpad * D / 4));
+    TRY(g->alloc(&g->x2, Mpad * D / 4));
     TRY(g->alloc(&g->y, Mpad * D / 4));
     TRY(g->alloc(&g->hbuf, Mpad * 4 * D / 4));
     TRY(g->alloc(&g->slabs, (size_t)MAX_SLABS * Mpad * D / 4));
     TRY(g->alloc(&g->qkv_slabs, (size_t)MAX_SLABS * Mpad * 3 * D / 4));
     TRY(g->alloc(&g->qbuf, Mpad * D));
     TRY(g->alloc(&g->stats, (size_t)STAT_CHUNKS_MAX * Mpad * 2));
+    TRY(g->alloc(&g->stats_q, (size_t)QKV_SLABS_MAX * Mpad * 2));
     const size_t kv = (size_t)L * g->Bmax * H * g->Tmax * hd;
     TRY(g->alloc(&g->kcache, kv));
     TRY(g->alloc(&g->vcache, kv));
@@ -410,6 +465,7 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
     if (rc == WMAR_OK) {
         // padded rows of the packed buffers must hold finite numbers
         hipError_t e = hipMemsetAsync(g->x, 0, Mpad * D * 4, st);
+        if (e == hipSuccess) e = hipMemsetAsync(g->x2, 0, Mpad * D * 4, st);
         if (e == hipSuccess) e = hipMemsetAsync(g->kcache, 0, kv * 4, st);
         if (e == hipSuccess) e = hipMemsetAsync(g->vcache, 0, kv * 4, st);
         if (e == hipSuccess) e = hipMemsetAsync(g->hbuf, 0, Mpad * 4 * D * 4, st);
@@ -438,7 +494,7 @@ int wmar_gpt_decode_step(wmar_gpt* g, const int64_t* tok_dev, int64_t B, int32_t
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, g->pos_dev, (int)pos);
     StepIO io{(const long long*)tok_dev, 1, 0, logits_dev};
-    g->att_nw = wmar_gpt::phase_waves(wmar_gpt::att_phase(pos + 1));
+    g->att_nw = wmar_gpt::phase_waves(g->att_phase(pos + 1));
     return enqueue_step(g, B, io, st);
 }
 
@@ -450,16 +506,18 @@ int wmar_gpt_profile_role(wmar_gpt* g, int32_t role, int64_t B, int32_t kv_len, 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, g->pos_dev, (int)kv_len - 1);
     StepIO io{g->past, (long long)g->Tmax + 1, 0, g->logits};
-    g->att_nw = wmar_gpt::phase_waves(wmar_gpt::att_phase(kv_len));
+    g->att_nw = wmar_gpt::phase_waves(g->att_phase(kv_len));
     StepPlan p(g, B, io, st);
     // dev knob: WMAR_PROFILE_LAYERS=n cycles through the first n layers only (n = 1: weights stay in the memory-side cache)
-    const char* pl = getenv("WMAR_PROFILE_LAYERS");
-    const int ncycle = pl && atoi(pl) > 0 ? std::min(atoi(pl), g->L) : g->L;
+    int ncycle = g->L;
+#ifdef WMAR_DEV_KNOBS
+    { const char* pl = getenv("WMAR_PROFILE_LAYERS"); if (pl && atoi(pl) > 0) ncycle = std::min(atoi(pl), g->L); }
+#endif
     auto one = [&](int it) -> int {
         const int l = it % ncycle;
         switch (role) {
             case WMAR_T_EMBED: return p.embed();
-            case WMAR_T_QKV: return p.qkv(l);
+            case WMAR_T_QKV: p.xcur = g->x; return p.S_qx > 0 ? p.qkvx(l, g->layers[l].bfc2) : p.qkv(l);
             case WMAR_T_ATTN: return p.attn(l);
             case WMAR_T_PROJ: return p.proj(l);
             case WMAR_T_RESID: return p.resid(g->layers[l].bproj, p.S_proj);
@@ -482,6 +540,13 @@ int wmar_gpt_profile_role(wmar_gpt* g, int32_t role, int64_t B, int32_t kv_len, 
     float ms = 0.f;
     WMAR_HIP_CHECK(hipEventElapsedTime(&ms, g->ev0, g->ev1));
     *avg_us = (double)ms * 1000.0 / iters;
+    return WMAR_OK;
+}
+
+int wmar_gpt_set_attention_phases(wmar_gpt* g, int32_t one_wave_upto, int32_t two_waves_upto) {
+    WMAR_REQUIRE(g && one_wave_upto >= 0 && two_waves_upto >= one_wave_upto, "set_attention_phases: bad thresholds");
+    if (g->att_t1 != one_wave_upto || g->att_t2 != two_waves_upto) g->drop_graph();
+    g->att_t1 = one_wave_upto; g->att_t2 = two_waves_upto;
     return WMAR_OK;
 }
 
@@ -557,9 +622,15 @@ int wmar_gpt_generate(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_para
                                       0ull, 0ull, (unsigned long long)sp->top_k, 0ull};
         float fd = wm ? wm->delta : 0.f, ft = sp->temperature;
         memcpy(&key[8], &fd, 4); memcpy(&key[9], &ft, 4); memcpy(&key[11], &sp->top_p, 8);
-        if (g->exec[0] && memcmp(key, g->graph_key, sizeof(key)) != 0) g->drop_graph();
-        if (!g->exec[0]) {
+        if (memcmp(key, g->graph_key, sizeof(key)) != 0) g->drop_graph();
+        bool need[wmar_gpt::N_PHASE] = {false, false, false};
+        for (int n = 0; n < steps; ++n) need[g->att_phase(n + 1)] = true;
+        bool have = true;
+        for (int ph = 0; ph < wmar_gpt::N_PHASE; ++ph) have = have && (!need[ph] || g->exec[ph]);
+        if (!have) {
+            g->drop_graph();
             for (int ph = 0; ph < wmar_gpt::N_PHASE; ++ph) {
+                if (!need[ph]) continue;          // only the phases this run passes through are captured
                 WMAR_HIP_CHECK(hipStreamBeginCapture(g->cap_stream, hipStreamCaptureModeThreadLocal));
                 int rc = one_step(g->cap_stream, ph);
                 hipError_t e = hipStreamEndCapture(g->cap_stream, &g->graph[ph]);
@@ -571,7 +642,7 @@ int wmar_gpt_generate(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_para
             memcpy(g->graph_key, key, sizeof(key));
         }
         hipError_t e = hipSuccess;
-        for (int n = 0; n < steps && e == hipSuccess; ++n) e = hipGraphLaunch(g->exec[wmar_gpt::att_phase(n + 1)], st);
+        for (int n = 0; n < steps && e == hipSuccess; ++n) e = hipGraphLaunch(g->exec[g->att_phase(n + 1)], st);
         if (e == hipSuccess) e = hipEventRecord(g->ev1, st);   // also marks "replays finished" for drop_graph()
         if (e == hipSuccess) { g->pending = true; }
         if (e != hipSuccess) { set_error("graph replay failed: %s", hipGetErrorString(e)); return WMAR_EHIP; }
@@ -580,7 +651,7 @@ int wmar_gpt_generate(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_para
     } else {
         g->span_on = g->timing != 0;
         int rc = WMAR_OK;
-        for (int n = 0; n < steps && rc == WMAR_OK; ++n) rc = one_step(st, wmar_gpt::att_phase(n + 1));
+        for (int n = 0; n < steps && rc == WMAR_OK; ++n) rc = one_step(st, g->att_phase(n + 1));
         g->span_on = false;
         if (rc) return rc;
         if (g->timing) {

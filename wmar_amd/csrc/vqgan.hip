@@ -709,7 +709,11 @@ bool in_attn_res(const wmar_vq_config& c, int res) {
     return false;
 }
 
+#ifdef WMAR_DEV_KNOBS
 static bool vq_trace() { static int v = -1; if (v < 0) { const char* e = getenv("WMAR_VQ_TRACE"); v = e ? atoi(e) : 0; } return v != 0; }
+#else
+static constexpr bool vq_trace() { return false; }
+#endif
 
 // Which tensor the per-tile statistics buffer currently describes.  Set by the conv that produced the tensor, consumed by the
 // next run_gn on it; one call (decode / encode) at a time per thread.

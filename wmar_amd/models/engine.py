@@ -89,6 +89,10 @@ class GPTEngine:
                                                      _lib.stream_ptr(self.device), C.byref(out)))
         return out.value
 
+    def set_attention_phases(self, one_wave_upto: int, two_waves_upto: int):
+        """Cache lengths up to which the decode attention runs 1 / 2 waves per (sequence, head) (4 beyond)."""
+        _lib.check(self._L.wmar_gpt_set_attention_phases(self._h, int(one_wave_upto), int(two_waves_upto)))
+
     def set_timing(self, on: bool):
         self._L.wmar_gpt_set_timing(self._h, 1 if on else 0)
 
