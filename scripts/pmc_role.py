@@ -1,6 +1,6 @@
 """Dev tool for PMC passes: replays one decode role (default fc1) a few times."""
 import sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wmar_amd.utils import synth
 from wmar_amd.models.engine import GPTEngine
 role = sys.argv[1] if len(sys.argv) > 1 else "fc1"

@@ -732,6 +732,7 @@ struct AttnArgs {
     int D, H, Tmax, MT;
     float scale;
     int dbg;                   // dev builds only (-DWMAR_DEV_KNOBS, WMAR_ATT_DBG): 2 = skip K/V streaming
+    unsigned long long* trace; // dev only (WMAR_ATT_TRACE): 5 timestamps per workgroup
 };
 
 // One workgroup of NWA waves per (sequence, head).  The cached rows are cut into chunks of
@@ -774,6 +775,10 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
     }
     float4 kA[CH], vA[CH], kB[CH], vB[CH];
     float4 q, knew, vnew;
+#ifdef WMAR_ATT_TRACE
+    unsigned long long tr[5];
+    tr[0] = __builtin_amdgcn_s_memtime();
+#endif
     // PF2: the wave's first TWO chunks are requested before the prologue (32 KiB in flight per wave: with 1 / 2 / 4 waves the
     // whole cache up to 64 / 128 / 256 rows streams while q/k/v are finished); otherwise one, the second from inside the loop
     if (w < nchunk) { WMAR_ATT_LOAD(kA, vA, w) }
@@ -810,6 +815,10 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
                 bb[which] = *(const float4*)(a.bias + n);
             }
         }
+#ifdef WMAR_ATT_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tr[1] = __builtin_amdgcn_s_memtime();
+#endif
         sm = st0.x; sq = st0.y;
         for (int c = lane + 64; a.mode == 0 && c < a.n_chunks; c += 64) {     // n_embd > 8192 only
             const double2 v = *(const double2*)(a.stats + ((long long)c * Mpad + b) * 2);
@@ -882,6 +891,9 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
         }
     }
     __syncthreads();
+#ifdef WMAR_ATT_TRACE
+    tr[2] = __builtin_amdgcn_s_memtime();
+#endif
     q = lane_on ? *(const float4*)(&qkv_s[0][sub * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
     knew = *(const float4*)(&qkv_s[1][sub * 4]);
     vnew = *(const float4*)(&qkv_s[2][sub * 4]);
@@ -927,6 +939,9 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
     }
 #undef WMAR_ATT_LOAD
 #undef WMAR_ATT_CHUNK
+#ifdef WMAR_ATT_TRACE
+    tr[3] = __builtin_amdgcn_s_memtime();
+#endif
     // fold the RPI row groups of this wave (l and acc are per-lane partials over the lane's rows)
 #pragma unroll
     for (int o = LPR; o < 64; o <<= 1) {
@@ -959,6 +974,13 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
         const int mt = b >> 5;
         a.y[((long long)kb * a.MT + mt) * 64 + (b & 31) + 32 * hf] = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
     }
+#ifdef WMAR_ATT_TRACE
+    if (a.trace && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tr[4] = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < 5; ++i) a.trace[(long long)blockIdx.x * 5 + i] = tr[i];
+    }
+#endif
 }
 
 }  // namespace wmar
