@@ -12,7 +12,7 @@ int main(int argc, char** argv) {
     const int D = 1536, MT = 2, S = argc > 1 ? atoi(argv[1]) : 7; const int S_IN = argc > 2 ? atoi(argv[2]) : 6;
     const int KB = D / 8, NT = 3 * D / 32;
     hipStream_t st; hipStreamCreate(&st);
-    const int NL = 12;                                           // distinct weight buffers: stream from HBM, not the MALL
+    const int NL = argc > 3 ? atoi(argv[3]) : 12;                                           // distinct weight buffers: stream from HBM, not the MALL
     std::vector<float4*> W(NL);
     for (auto& p : W) { hipMalloc(&p, (size_t)3 * D * D * 4); hipMemset(p, 0x3c, (size_t)3 * D * D * 4); }
     float4 *x, *x2, *slabs, *out; float* bias; double* stats; unsigned long long* tr;
@@ -25,9 +25,10 @@ int main(int argc, char** argv) {
     hipMalloc(&stats, 8 * 64 * 2 * 8);
     const int total = (NT / 4) * S, cap = (total + 7) / 8;
     hipMalloc(&tr, (size_t)total * 4 * 4 * 8);
+    unsigned long long* trc; hipMalloc(&trc, (size_t)total * 4 * 8 * 8);
     QkvxArgs q{};
     q.x_in = x; q.x_out = x2; q.slabs = slabs; q.slab_stride = (long long)act; q.n_hi = 16; q.bias = bias; q.stats = stats;
-    q.out = out; q.out_stride = 3 * (long long)act; q.KB = KB; q.NT = NT; q.S = S; q.cap = cap; q.trace = tr;
+    q.out = out; q.out_stride = 3 * (long long)act; q.KB = KB; q.NT = NT; q.S = S; q.cap = cap; q.trace = tr; q.trace_chunks = trc;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
         hipMemset(tr, 0, (size_t)total * 4 * 4 * 8);
@@ -56,5 +57,12 @@ int main(int argc, char** argv) {
         printf("wg %3d (s=%d g=%2d) wave0: entry %5llu  +stage %5llu  +loop %5llu  +store %5llu\n", j, j / (NT / 4), j % (NT / 4),
                h[(size_t)j * 16] - t0, h[(size_t)j * 16 + 1] - h[(size_t)j * 16], h[(size_t)j * 16 + 2] - h[(size_t)j * 16 + 1],
                h[(size_t)j * 16 + 3] - h[(size_t)j * 16 + 2]);
+    std::vector<unsigned long long> hc((size_t)total * 32);
+    hipMemcpy(hc.data(), trc, hc.size() * 8, hipMemcpyDeviceToHost);
+    double avg[8] = {0}; int cnt[8] = {0};
+    for (int i = 0; i < total * 4; ++i) for (int c = 0; c < 8; ++c) if (c == 0 || hc[(size_t)i * 8 + c]) { avg[c] += hc[(size_t)i * 8 + c]; cnt[c]++; }
+    printf("chunk start (ticks after the first barrier), avg over waves:");
+    for (int c = 0; c < 8; ++c) printf(" %.0f", cnt[c] ? avg[c] / cnt[c] : 0.0);
+    printf("\n");
     return 0;
 }

@@ -48,6 +48,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     # development builds only (tuning scripts under scripts/): environment-variable knobs compiled in
     dev = ["-DWMAR_DEV_KNOBS"] if os.environ.get("WMAR_DEV_KNOBS") else []
+    dev += os.environ.get("WMAR_EXTRA_HIPCC_FLAGS", "").split()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     srcs = [(s, f) for s, f in SOURCES if os.path.exists(os.path.join(CSRC, s))]

@@ -20,6 +20,9 @@ constexpr int MAX_SLABS = 8;
 constexpr int QKV_SLABS_MAX = 8;   // the QKV projection arrives in at most 8 split-K pieces
 constexpr int STAT_CHUNKS_MAX = 64;   // n_embd <= 8192
 constexpr int GEMM_STAGE = 4;   // k-blocks (of 8) per register stage of the skinny GEMM
+#ifndef WMAR_GEMM_INTERLEAVE
+#define WMAR_GEMM_INTERLEAVE 2   // MFMAs between two operand loads of the main loop (0: loads in one batch per stage)
+#endif
 
 // ------------------------------------------------------------------------ weight packing
 // gamma (nullable): the LayerNorm scale of the layer that feeds this Linear, folded into
@@ -334,6 +337,28 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tr1 = __builtin_amdgcn_s_memtime();
 #endif
+#if WMAR_GEMM_INTERLEAVE > 0
+        // one load between every WMAR_GEMM_INTERLEAVE MFMAs: a wave issues in order, so a batch of loads in front of the MFMAs
+        // keeps the matrix pipe idle for as long as the batch takes to issue (~30 cycles per 1 KiB load); one load fits in the
+        // 64-cycle shadow of an MFMA
+#define WMAR_INTERLEAVE()                                                                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < U * (1 + MTW); ++i_) {                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, WMAR_GEMM_INTERLEAVE, 0);                  \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                     \
+        }                                                                                          \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * U * MTW - WMAR_GEMM_INTERLEAVE * U * (1 + MTW), 0);
+        for (int it = 0; it < nfull; ++it) {
+            WMAR_LOAD(wB, xB, WMAR_STAGE_KB(2 * it + 1))
+            WMAR_MMA(wA, xA)
+            WMAR_INTERLEAVE()
+            __builtin_amdgcn_sched_barrier(0);
+            WMAR_LOAD(wA, xA, WMAR_STAGE_KB((2 * it + 2) % nst))
+            WMAR_MMA(wB, xB)
+            WMAR_INTERLEAVE()
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef WMAR_INTERLEAVE
+#else
         for (int it = 0; it < nfull; ++it) {
             WMAR_LOAD(wB, xB, WMAR_STAGE_KB(2 * it + 1))
             __builtin_amdgcn_sched_barrier(0);
@@ -345,6 +370,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
             WMAR_MMA(wB, xB)
             __builtin_amdgcn_sched_barrier(0);
         }
+#endif
 #undef WMAR_STAGE_KB
         kb = kb0 + nst * U;
     } else {
@@ -386,21 +412,24 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
     tr2 = __builtin_amdgcn_s_memtime();
 #endif
     // in-workgroup K reduction (fixed order) + epilogue
-    float* my = smem + (long long)w * (MTW * 16) * 64;
+    // 16-byte LDS accesses: a wave parks its accumulators as MTW*4 float4 rows (the 4 registers of one output group are
+    // adjacent) and the reducing wave reads one float4 per partner -- a quarter of the LDS instructions of a dword layout
+    float4* smem4 = reinterpret_cast<float4*>(smem);
 #pragma unroll
     for (int i = 0; i < MTW; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) my[(i * 16 + r) * 64 + lane] = acc[i][r];
+        for (int g4 = 0; g4 < 4; ++g4)
+            smem4[((long long)w * (MTW * 4) + i * 4 + g4) * 64 + lane] =
+                make_float4(acc[i][g4 * 4 + 0], acc[i][g4 * 4 + 1], acc[i][g4 * 4 + 2], acc[i][g4 * 4 + 3]);
     __syncthreads();
 
     for (int grp = w; grp < MTW * 4; grp += NW) {
         const int i = grp >> 2, g = grp & 3;
-        float o[4];
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float t = 0.f;
-            for (int ww = 0; ww < NW; ++ww) t += smem[((long long)ww * (MTW * 16) + i * 16 + g * 4 + j) * 64 + lane];
-            o[j] = t;
+        for (int ww = 0; ww < NW; ++ww) {
+            const float4 t = smem4[((long long)ww * (MTW * 4) + i * 4 + g) * 64 + lane];
+            o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
         }
         const int mt = mt0 + i;
         const int n = nt * 32 + g * 8 + half * 4;       // first of 4 consecutive output columns
@@ -462,6 +491,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
 //   * every wave stores its accumulators as one of S split-K pieces, which the attention prologue sums in slice order.
 // Weights: a wave walks its own column tile, loads issued two chunks (2 x 2048 MFMA cycles) ahead of use.
 constexpr int QX_CK = 4;      // k-blocks per chunk (one staged by each wave)
+#ifndef QX_ABL
+#define QX_ABL 0     // dev ablations (trace builds): 1 = no weight loads in the loop, 2 = no chunk barriers, 4 = no LDS reads in the loop
+#endif
+#define WMAR_QX_SYNC() if (!(QX_ABL & 2)) __syncthreads();
+#ifndef QX_SPLIT
+#define QX_SPLIT 2             // k-blocks multiplied before the chunk barrier; the next chunk's LDS reads land under the rest
+#endif
 
 struct QkvxArgs {
     const float4* Wp;          // [NT][KB][64] gamma-folded QKV weights
@@ -476,6 +512,7 @@ struct QkvxArgs {
     long long out_stride;      // float4 units
     int KB, NT, S, cap;        // cap: workgroup slots per XCD (grid = 8 * cap)
     unsigned long long* trace; // dev only (WMAR_QX_TRACE): 4 timestamps per wave
+    unsigned long long* trace_chunks;   // dev only: start of each chunk relative to the first, per wave
 };
 
 // MTW = row tiles (all of them: MT == MTW); S_IN = slabs folded into x (0: x is used as it is, layer 0).  Both are template
@@ -568,13 +605,13 @@ __global__ __launch_bounds__(512) void k_qkvx(QkvxArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             WMAR_QX_ISSUE(xvB, bbB, slB, skbB, c + 3)
             __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();                               // barrier(c)
+            WMAR_QX_SYNC()                                 // barrier(c)
             if (c + 2 >= nch) break;
             WMAR_QX_FINISH(xvA, bbA, slA, skbA, 0)         // chunk c+2
             __builtin_amdgcn_sched_barrier(0);
             WMAR_QX_ISSUE(xvA, bbA, slA, skbA, c + 4)
             __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();                               // barrier(c+1)
+            WMAR_QX_SYNC()                                 // barrier(c+1)
         }
 #undef WMAR_QX_ISSUE
 #undef WMAR_QX_FINISH
@@ -599,6 +636,9 @@ __global__ __launch_bounds__(512) void k_qkvx(QkvxArgs a) {
     }
 
     // ------------------------------------------------------------------------------------------ multiplying waves
+#ifdef QX_PRIO
+    __builtin_amdgcn_s_setprio(QX_PRIO);
+#endif
     const int nt = g * 4 + w;
     f32x16 acc[MTW];
 #pragma unroll
@@ -631,21 +671,28 @@ __global__ __launch_bounds__(512) void k_qkvx(QkvxArgs a) {
         }
 // one chunk: request the weights three chunks ahead, multiply three k-blocks, pass the chunk barrier and read the next chunk's
 // fragments, multiply the last k-block
+#ifdef WMAR_QX_TRACE
+#define WMAR_QX_STAMP(C) if ((C) < 8) trc[(C)] = __builtin_amdgcn_s_memtime();
+#else
+#define WMAR_QX_STAMP(C)
+#endif
 #define WMAR_QX_STEP(C, WCUR, WFAR, XCUR, XNEXT, BUFNEXT)                                              \
-    WMAR_QX_W(WFAR, (C) + 3)                                                                            \
+    WMAR_QX_STAMP(C)                                                                                    \
+    if (!(QX_ABL & 1)) { WMAR_QX_W(WFAR, (C) + 3) }                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
-    WMAR_QX_MMA(WCUR, XCUR, C, 0, QX_CK - 1)                                                            \
+    WMAR_QX_MMA(WCUR, XCUR, C, 0, QX_SPLIT)                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
     if ((C) + 1 < nch) {                                                                                \
-        __syncthreads();                                                                                \
-        WMAR_QX_READ(XNEXT, BUFNEXT)                                                                    \
+        WMAR_QX_SYNC()                                                                                  \
+        if (!(QX_ABL & 4)) { WMAR_QX_READ(XNEXT, BUFNEXT) }                                             \
     }                                                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
-    WMAR_QX_MMA(WCUR, XCUR, C, QX_CK - 1, QX_CK)                                                        \
+    WMAR_QX_MMA(WCUR, XCUR, C, QX_SPLIT, QX_CK)                                                         \
     __builtin_amdgcn_sched_barrier(0);
 
 #ifdef WMAR_QX_TRACE
     const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
+    unsigned long long trc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     WMAR_QX_W(w0, 0)
     WMAR_QX_W(w1, 1)
@@ -686,6 +733,7 @@ __global__ __launch_bounds__(512) void k_qkvx(QkvxArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned long long* t = a.trace + ((long long)j * 4 + w) * 4;
         t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = __builtin_amdgcn_s_memtime();
+        if (a.trace_chunks) for (int i = 0; i < 8; ++i) a.trace_chunks[((long long)j * 4 + w) * 8 + i] = trc[i] ? trc[i] - tr1 : 0;
     }
 #endif
 }
