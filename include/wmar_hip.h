@@ -272,6 +272,8 @@ typedef struct wmar_cham_sample_params {
     double top_p;                                     /* < 0: off */
     float guidance_scale_text, guidance_scale_image;  /* Options.Image.cfg: 3.0 / 1.2 */
     int32_t use_graph;
+    int32_t pad_id;   /* vocab.pad_id: what AlignPromptRight pads short prompts with on the left (alignment.py:27-41); the
+                       * watermark context of the first image tokens can reach into it when context_size >= 2 */
 } wmar_cham_sample_params;
 
 typedef struct wmar_cham wmar_cham;
@@ -295,7 +297,9 @@ int wmar_cham_forward_tokens(wmar_cham* g, const int64_t* tok_dev, const int32_t
  * [n_allow], nullable -- with it the sampler works on the compacted row, which is exact) -> temperature -> top-p -> softmax ->
  * multinomial on the first stream (q_dev float [n_tokens, B, vocab] Exp(1) noise, one [B, vocab]
  * draw per token as probs.multinomial makes).  tokens_out_dev int64 [B, n_tokens] (vocabulary ids).
- * The watermark context is the sequence so far (last prompt token first). */
+ * The watermark context is the whole right-aligned input row, as the reference's processors see it (generation.py:86): its
+ * last 3 entries (prompt tokens, left-padded with pad_id) are kept in front of the generated tokens, enough for every linear
+ * context size the library supports (<= 3).  SPATIAL seeding is rejected: the reference does not offer it for Chameleon. */
 int wmar_cham_generate_image(wmar_cham* g, const wmar_wm_ctx* wm, const int64_t* prompt_tokens_host,
                              const int32_t* prompt_lens_host, int64_t B, const wmar_cham_sample_params* sp,
                              const uint32_t* allow_dev, const int32_t* allow_ids_dev, int32_t n_allow, const float* q_dev,

@@ -218,6 +218,39 @@ def chameleon_vectors(args):
         out[f"cham_{name}_tok"] = tok[:B].numpy().astype(np.int64)
         out[f"cham_{name}_q"] = q.numpy()
         out[f"cham_{name}_params"] = np.array([h, delta, temp, top_p], dtype=np.float64)
+    # ---- text-mode logits chain of TextDecoder._logits_processors (chameleon.py:262-284) for the interleaved mode: text
+    # watermark -> allow-only (eos + text tokens + <boi>) -> DisallowTokensAtOrAfterIndex([boi], max_seq_len - 1026) ->
+    # HF RepetitionPenalty(1.2) -> Temperature(0.7) -> TopP(0.9) -> MultinomialTokenSelector (token_selector.py:26-31)
+    from transformers import RepetitionPenaltyLogitsProcessor
+    from deps.chameleon.inference.logits_processor import DisallowTokensAtOrAfterIndexLogitsProcessor
+    Bt = 6
+    gt = torch.Generator().manual_seed(78)                         # its own stream: the fixtures below keep their values
+    tl = (torch.randn(Bt, V, generator=gt) * 2.5).bfloat16().float()
+    tin = torch.randint(0, V, (Bt, 9), generator=gt)
+    tin[0, :3] = vi.pad_id                                         # left padding of a shorter prompt
+    tin[1, 4] = tin[1, 7]                                           # a repeated token
+    allowed = [vi.eos_id] + vi.text_tokens + [vi.begin_image]
+    out["cham_text_logits"] = tl.numpy()
+    out["cham_text_input_ids"] = tin.numpy()
+    out["cham_text_allowed"] = np.array(allowed, dtype=np.int64)
+    for name, seed_s, h, limit in [("wm", SeedStrategy.LINEAR, 1, 100), ("nowm_limit", None, 0, 9), ("fixed", SeedStrategy.FIXED, 0, 100)]:
+        procs = []
+        if seed_s is not None:
+            wmt = GentimeWatermark(vq, V, seed_s, SplitStrategy.RANDOM_STRATIFIED, h, 2.0, 0.25, device="cpu")
+            procs.append(wmt.spawn_logit_processor())
+        procs += [AllowOnlyTokensLogitsProcessor(allowed), DisallowTokensAtOrAfterIndexLogitsProcessor([vi.begin_image], limit),
+                  RepetitionPenaltyLogitsProcessor(1.2), TemperatureLogitsWarper(0.7), TopPLogitsWarper(0.9)]
+        lgt = LogitsProcessorList(procs)(tin, tl.clone())
+        probs = lgt.softmax(dim=1)
+        torch.manual_seed(4321)
+        tokt = MultinomialTokenSelector()(tin, probs)
+        torch.manual_seed(4321)
+        qt = torch.empty(Bt, V).exponential_(1)
+        assert torch.equal(tokt, (probs / qt).argmax(dim=1))
+        out[f"cham_text_{name}_processed"] = lgt.numpy()
+        out[f"cham_text_{name}_tok"] = tokt.numpy().astype(np.int64)
+        out[f"cham_text_{name}_limit"] = np.array(limit)
+    out["cham_text_q"] = qt.numpy()
     # ---- the image tokenizer side: Chameleon's own VQGAN (deps/chameleon/inference/vqgan.py) on a reduced config with the
     # released model's topology (no attention in the down/up path, one in the middle).  image_tokenizer.py itself does not
     # import under this Python (it annotates with the PIL.Image MODULE inside typing.Union).
@@ -537,6 +570,22 @@ def harness_vectors(args):
         out[f"{tag}_l0"] = np.array([m["l0"] for m in metrics], dtype=np.float64)
         out[f"{tag}_psnr"] = np.array([m["psnr"] for m in metrics], dtype=np.float64)
         out[f"{tag}_png"] = np.stack(pngs)
+        if tag == "job":
+            # f3: the reference's own result-directory reader and its TPR rule (wmar/utils/analyzer.py:186-238; the rule
+            # `np.sum(np.array(pvals) < 0.01) / len(pvals)` is inline in plot_robustness :376-381, :419-424)
+            from wmar.utils.analyzer import Analyzer
+            _, am, paths, N = Analyzer.get_metrics_imagepaths_N([("roundtrips", None, [0, 1])], "lbl", os.path.dirname(d),
+                                                                 os.path.basename(d), str(wm))
+            out["an_N"] = np.array(N)
+            out["an_keys"] = np.array(sorted(am))
+            for k in sorted(am):
+                pv = [m["pvalue"] for m in am[k]]
+                out[f"an_{k}_pvalues_sorted"] = np.array(sorted(pv), dtype=np.float64)
+                out[f"an_{k}_l0_sorted"] = np.array(sorted(m["l0"] for m in am[k]), dtype=np.float64)
+                for thr in (0.01, 0.25):
+                    out[f"an_{k}_tpr_at_{thr}"] = np.array(np.sum(np.array(pv) < thr) / len(pv))
+            out["an_orig_image_classes"] = np.array(sorted(paths))
+            out["an_orig_images_per_class"] = np.array([len(paths[c]) for c in sorted(paths)])
         shutil.rmtree(d)
 
     run(0, 1, "job")
@@ -586,20 +635,57 @@ def harness_vectors(args):
         print(k, out[k])
 
 
+def spatial_vectors(args):
+    """f4: the reference's sampling loop (mingpt.py:326-368) under SeedStrategy.SPATIAL (gentime_watermark.py:242-263): h = 1
+    (context = the token above at row starts, else the previous token) and h = 3 (up-left, up, left), spatial_dim 4, 16 steps
+    of the 2-layer / 128-wide GPT of the other loop fixtures.  Exercises the SPATIAL branch of the fused sampler inside the
+    captured generation step."""
+    import torch
+    from deps.taming.modules.transformer.mingpt import GPT, sample_with_past
+    from wmar.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
+    from wmar_amd.utils import synth
+    import contextlib, io
+
+    ids = []
+    for line in open(os.path.join(args.ref, "assets", "vqgan_alive_ids.txt")):
+        ids.extend(int(t) for t in line.split(","))
+    dead = list(set(range(16384)) - set(ids))
+    vq = {"alive_ids": torch.tensor(ids), "dead_ids": torch.tensor(dead), "embedding": torch.zeros(16384, 4)}
+    cfg = synth.GPTConfig(vocab_size=16384, block_size=16, n_layer=2, n_head=4, n_embd=128)
+    sd = synth.synth_gpt_state(cfg, seed=3, logit_scale=40.0, with_mask=True)
+    gpt = GPT(vocab_size=cfg.vocab_size, block_size=cfg.block_size, n_layer=cfg.n_layer, n_head=cfg.n_head, n_embd=cfg.n_embd)
+    gpt.load_state_dict(sd, strict=True)
+    gpt.eval()
+    cond = torch.tensor([[7], [980], [1], [340]], dtype=torch.long)
+    out = {"cond": cond.numpy()}
+    for h in (1, 3):
+        wm = GentimeWatermark(vq, 16384, SeedStrategy.SPATIAL, SplitStrategy.RANDOM_STRATIFIED, h, 2.0, 0.25, spatial_dim=4)
+        torch.manual_seed(11)
+        with contextlib.redirect_stdout(io.StringIO()):
+            toks = sample_with_past(cond, gpt, steps=16, temperature=1.0, sample_logits=True, top_k=250, top_p=0.92,
+                                    logit_processor=wm.spawn_logit_processor())
+            pv, masks = wm.detect(toks, return_masks=True)
+        out[f"tokens_h{h}"] = toks.numpy()
+        out[f"pvals_h{h}"] = pv.numpy()
+        out[f"masks_h{h}"] = np.array(masks, dtype=np.int8)
+    np.savez_compressed(os.path.join(HERE, "spatial_vectors.npz"), **out)
+    print("wrote spatial_vectors.npz", os.path.getsize(os.path.join(HERE, "spatial_vectors.npz")), "bytes")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--only", default="", help="'gumbel' / 'chameleon' / 'prod' / 'sampler' / 'harness': regenerate only that fixture file")
+    ap.add_argument("--only", default="", help="'gumbel' / 'chameleon' / 'prod' / 'sampler' / 'harness' / 'spatial': regenerate only that fixture file")
     args = ap.parse_args()
     if args.only == "gumbel":
         gumbel_vectors(args)
         return
-    if args.only in ("chameleon", "prod", "sampler", "harness"):
+    if args.only in ("chameleon", "prod", "sampler", "harness", "spatial"):
         tmp = tempfile.mkdtemp(prefix="wmar_stubs_")
         _stubs(tmp)
         sys.path[:0] = [tmp, args.ref, REPO]
         os.chdir(args.ref)
-        {"chameleon": chameleon_vectors, "prod": prod_vectors, "sampler": sampler_bulk_vectors, "harness": harness_vectors}[args.only](args)
+        {"chameleon": chameleon_vectors, "prod": prod_vectors, "sampler": sampler_bulk_vectors, "harness": harness_vectors, "spatial": spatial_vectors}[args.only](args)
         return
     tmp = tempfile.mkdtemp(prefix="wmar_stubs_")
     _stubs(tmp)
@@ -829,6 +915,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     sz = os.path.getsize(os.path.join(HERE, "reference_vectors.npz"))
     print("wrote reference_vectors.npz", sz, "bytes; key_kat.json")
+    spatial_vectors(args)
     harness_vectors(args)      # last: it plants placeholder modules for generate.py's unrelated imports
 
 

@@ -106,10 +106,12 @@ def test_cham_sample_reference_tokens(cv, name, seed, compact):
     assert np.array_equal(out.cpu().numpy(), cv[f"cham_{name}_tok"])
 
 
-@pytest.mark.parametrize("graph", [True, False])
-def test_generate_image_loop(graph):
+@pytest.mark.parametrize("graph,h", [(True, 1), (False, 1), (True, 2), (True, 3)])
+def test_generate_image_loop(graph, h):
     """The captured generation loop: every sampled token equals the oracle's sampling chain applied to the engine's own
-    step logits (same prompts, same tokens fed back), with ragged prompts, a LINEAR watermark and top-p."""
+    step logits (same prompts, same tokens fed back), with ragged prompts, a LINEAR watermark and top-p.  The watermark context
+    is the right-aligned, left-padded input row as the reference's processors see it: with h = 2 the first image token's context
+    is the last two prompt tokens, and a prompt shorter than the context would reach into the padding."""
     from wmar_amd.models.chameleon_wrapper import ChameleonARMMWrapper
     from wmar_amd.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
     from oracle import wm_oracle as W
@@ -122,7 +124,7 @@ def test_generate_image_loop(graph):
                              max_batch=3, max_prompt_len=16)
     assert m.n_image_tokens == 64
     m.use_graph = graph
-    wm = GentimeWatermark(m.get_vq(), 2048, SeedStrategy.LINEAR, SplitStrategy.RANDOM_STRATIFIED, 1, 3.0, 0.25, device="cuda")
+    wm = GentimeWatermark(m.get_vq(), 2048, SeedStrategy.LINEAR, SplitStrategy.RANDOM_STRATIFIED, h, 3.0, 0.25, device="cuda")
     m.set_watermarker(wm)
     text = m.vocab.text_tokens
     cond = [(0, [text[5], text[9], text[100]]), (1, [text[7]]), (2, [text[1], text[2], text[3], text[4], text[400]])]
@@ -141,8 +143,9 @@ def test_generate_image_loop(graph):
         tok = [p[j - (maxlen - len(p))] if j - (maxlen - len(p)) >= 0 else 0 for p in prompts]
         pos = [max(j - (maxlen - len(p)), 0) for p in prompts]
         lg = e2.forward_tokens(torch.tensor(tok).cuda(), torch.tensor(pos, dtype=torch.int32).cuda())
-    key = W.KeyParams(wm._alive_host, wm._dead_host, 2048, 0.25, seed="linear")
-    past = np.array([[p[-1]] for p in prompts[:3]], dtype=np.int64)
+    key = W.KeyParams(wm._alive_host, wm._dead_host, 2048, 0.25, seed="linear", context_size=h)
+    padded = [[m.vocab.pad_id] * (maxlen - len(p)) + list(p) for p in prompts[:3]]        # AlignPromptRight, alignment.py:27-41
+    past = np.array(padded, dtype=np.int64)
     pos = torch.tensor([len(p) for p in prompts], dtype=torch.int32)
     for n in range(64):
         tok, _ = CO.sample_step(lg.cpu(), q[n].cpu().numpy(), 0.9, 0.8, 3.0, 1.2, allow_ids=m.vocab.image_tokens, key=key, past_ids=past,

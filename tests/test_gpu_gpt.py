@@ -86,3 +86,22 @@ def test_generate_trace_and_determinism(kat, small_engine):
         exp = W.sample_rows(lg, q[n].cpu().numpy(), 1.0, 250, 0.92)
         assert exp.tolist() == t1[:, n].cpu().tolist(), n
         past = np.concatenate([past, exp[:, None]], axis=1)
+
+
+@pytest.mark.parametrize("h", [1, 3])
+@pytest.mark.parametrize("graph", [True, False])
+def test_generate_spatial_seeding_reproduces_reference_tokens(kat, small_engine, h, graph):
+    """SeedStrategy.SPATIAL inside the captured step (the fused sampler's spatial context branch): the reference's loop with
+    spatial_dim 4, h = 1 and h = 3 (tests/golden/spatial_vectors.npz, make_golden.py spatial_vectors)."""
+    import os
+    from tests.conftest import REPO
+    sv = np.load(os.path.join(REPO, "tests", "golden", "spatial_vectors.npz"))
+    eng, _ = small_engine
+    wm = _wm(kat["keys"]["taming"], seed="spatial", h=h, spatial_dim=4)
+    torch.manual_seed(11)
+    q = torch.stack([torch.empty(4, 16384).exponential_(1) for _ in range(16)]).cuda()
+    toks = eng.generate(torch.from_numpy(sv["cond"]).view(-1).cuda(), 16, q, 1.0, 250, 0.92, wm.wm_ctx(), use_graph=graph)
+    assert np.array_equal(toks.cpu().numpy(), sv[f"tokens_h{h}"])
+    pv, masks = wm.detect(toks, return_masks=True)
+    assert np.allclose(pv.cpu().numpy(), sv[f"pvals_h{h}"], rtol=1e-9, atol=0, equal_nan=True)
+    assert np.array_equal(np.array(masks, dtype=np.int8), sv[f"masks_h{h}"])

@@ -200,3 +200,22 @@ def test_vqgan(golden):
     np.testing.assert_allclose(z.numpy(), golden["vq_prequant"], rtol=0, atol=1e-5)
     codes = M.images_to_codes(sd, SMALL_VQ, torch.from_numpy(golden["vq_images"]))
     assert np.array_equal(codes.numpy(), golden["vq_codes_roundtrip"])
+
+
+def test_oracle_spatial_loop_reproduces_reference_tokens(kat, key_factory):
+    """the oracle's sampling loop under SPATIAL seeding equals the reference's (tests/golden/spatial_vectors.npz)."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import model_oracle as M
+    from tests.conftest import REPO
+    from wmar_amd.utils import synth
+    sv = np.load(os.path.join(REPO, "tests", "golden", "spatial_vectors.npz"))
+    cfg = synth.GPTConfig(vocab_size=16384, block_size=16, n_layer=2, n_head=4, n_embd=128)
+    sd = synth.synth_gpt_state(cfg, seed=3, logit_scale=40.0)
+    for h in (1, 3):
+        key = key_factory(kat["keys"]["taming"], seed="spatial", context_size=h, spatial_dim=4)
+        torch.manual_seed(11)
+        q = [torch.empty(4, 16384).exponential_(1) for _ in range(16)]
+        toks = M.sample_with_past(sd, cfg.n_head, torch.from_numpy(sv["cond"]), 16, 1.0, 250, 0.92, key, 2.0, q_source=lambda n, b, v: q[n])
+        assert np.array_equal(toks.numpy(), sv[f"tokens_h{h}"]), h

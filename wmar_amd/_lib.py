@@ -78,7 +78,7 @@ class ChamConfig(C.Structure):
 
 class ChamSampleParams(C.Structure):
     _fields_ = [("temperature", C.c_float), ("top_p", C.c_double), ("guidance_scale_text", C.c_float),
-                ("guidance_scale_image", C.c_float), ("use_graph", C.c_int32)]
+                ("guidance_scale_image", C.c_float), ("use_graph", C.c_int32), ("pad_id", C.c_int32)]
 
 
 class WmarError(RuntimeError):

@@ -299,7 +299,7 @@ int wmar_cham_create(const wmar_cham_config* cfg, const char* const* names, cons
     TRY(g->mem.alloc(&g->scratch, (size_t)g->Mmax * V));
     TRY(g->mem.alloc(&g->tok, Mpad));
     TRY(g->mem.alloc(&g->pos, Mpad));
-    TRY(g->mem.alloc(&g->ids, (size_t)g->Mmax * (size_t)(g->T + 1)));
+    TRY(g->mem.alloc(&g->ids, (size_t)g->Mmax * (size_t)(g->T + 4)));
     TRY(g->mem.alloc(&g->ctr, 4));
     TRY(g->mem.alloc(&g->rope, (size_t)g->T * (hd / 2)));
     if (rc == WMAR_OK) {
@@ -352,6 +352,8 @@ int wmar_cham_generate_image(wmar_cham* g, const wmar_wm_ctx* wm, const int64_t*
     WMAR_REQUIRE(n_tokens >= 1, "cham_generate_image: n_tokens");
     WMAR_REQUIRE(!(sp->top_p >= 0) || sp->top_p <= 1.0, "`top_p` has to be a float > 0 and < 1, but is %f", sp->top_p);
     if (wm) WMAR_REQUIRE(wm->table_dev && wm->vocab_size == g->V, "cham_generate_image: watermark vocab mismatch");
+    if (wm) WMAR_REQUIRE(wm->seed_strategy != WMAR_SEED_SPATIAL && wm->context_size <= 3,
+                         "Chameleon supports fixed / linear seeding with context size <= 3 (generate.py of the reference: fixed / linear only)");
     hipStream_t st = (hipStream_t)stream;
     const int M = 3 * (int)B, V = g->V;
     int maxlen = 0;
@@ -363,7 +365,9 @@ int wmar_cham_generate_image(wmar_cham* g, const wmar_wm_ctx* wm, const int64_t*
                  n_tokens, g->T);
     g->drop_graph();
     // right-aligned prompt tables (alignment.py:27-52): row m idles (token 0 at position 0) until its prompt starts
-    std::vector<long long> tt((size_t)maxlen * M), first_ctx((size_t)B);
+    // the watermark sees the whole padded row: keep its last CTX entries (prompt tokens, pad_id where the row is still padding)
+    const int CTX = maxlen < 3 ? maxlen : 3;
+    std::vector<long long> tt((size_t)maxlen * M), first_ctx((size_t)B * 3, 0);
     std::vector<int> tp((size_t)maxlen * M);
     size_t off = 0;
     for (int m = 0; m < M; ++m) {
@@ -375,7 +379,11 @@ int wmar_cham_generate_image(wmar_cham* g, const wmar_wm_ctx* wm, const int64_t*
             tt[(size_t)j * M + m] = tk;
             tp[(size_t)j * M + m] = i >= 0 ? i : 0;
         }
-        if (m < B) first_ctx[m] = prompt_tokens_host[off + len - 1];
+        if (m < B)
+            for (int c = 0; c < CTX; ++c) {
+                const int i = len - CTX + c;
+                first_ctx[(size_t)m * 3 + c] = i >= 0 ? prompt_tokens_host[off + i] : (long long)sp->pad_id;
+            }
         off += len;
     }
     long long* tab_tok = nullptr;
@@ -389,9 +397,9 @@ int wmar_cham_generate_image(wmar_cham* g, const wmar_wm_ctx* wm, const int64_t*
     int rc = WMAR_OK;
     hipError_t e = hipMemcpyAsync(tab_tok, tt.data(), tt.size() * 8, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(tab_pos, tp.data(), tp.size() * 4, hipMemcpyHostToDevice, st);
-    // the watermark context is the whole input row: its last prompt token, then the generated ones
-    const long long ids_stride = g->T + 1;
-    if (e == hipSuccess) e = hipMemcpy2DAsync(g->ids, ids_stride * 8, first_ctx.data(), 8, 8, (size_t)B, hipMemcpyHostToDevice, st);
+    // the watermark context is the whole input row: the tail of the padded prompt, then the generated tokens
+    const long long ids_stride = g->T + 4;
+    if (e == hipSuccess) e = hipMemcpy2DAsync(g->ids, ids_stride * 8, first_ctx.data(), 3 * 8, (size_t)CTX * 8, (size_t)B, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { set_error("cham_generate_image: %s", hipGetErrorString(e)); rc = WMAR_EHIP; }
     ChamPlan p(g, M, st);
@@ -400,7 +408,7 @@ int wmar_cham_generate_image(wmar_cham* g, const wmar_wm_ctx* wm, const int64_t*
                            (const long long*)nullptr, 0ll, (const int*)nullptr, (int)B, 0);
         rc = p.step(j == maxlen - 1, g->logits);
     }
-    hipLaunchKernelGGL(k_cham_set3, dim3(1), dim3(1), 0, st, g->ctr, 0, 0, 1);    // step = 0, len(ids row) = 1
+    hipLaunchKernelGGL(k_cham_set3, dim3(1), dim3(1), 0, st, g->ctr, 0, 0, CTX);    // step = 0, len(ids row) = CTX
     if (rc == WMAR_OK) rc = launch_status("k_set3");
 
     SampArgs a{};

@@ -6,7 +6,7 @@ What the reference spreads over ``ChameleonInferenceModel`` + a worker thread + 
 generation.py:21-102, model_adapter.py:36-119) is one engine call here: prompts are tokenised on the host
 (``TokenManager.tokens_from_ui``, chameleon.py:139-172), split into the three guidance streams (:351-372) and handed to
 ``ChameleonEngine.generate_image``; the worker thread, request queues and the watermarker-from-string round trip do not exist.
-Interleaved text+image generation (``sample_interleaved``) is not built.
+``sample_interleaved`` (text and image segments in one sequence) runs the same engine: eager text steps, captured image phases.
 """
 from __future__ import annotations
 
@@ -96,6 +96,8 @@ class ChameleonARMMWrapper(AutoregressiveMultimodalModelWrapper):
             vq.dead_ids = torch.tensor([t for t in range(cfg.vocab_size) if t not in alive], dtype=torch.long)
         self._allow_img = allow_bitmap(self.vocab.image_tokens, cfg.vocab_size, dev)
         self._allow_ids = torch.tensor(sorted(self.vocab.image_tokens), dtype=torch.int32, device=dev)
+        # TextDecoder._allowed_tokens (chameleon.py:255-261) with txt and img both on
+        self._allow_text = torch.tensor([self.vocab.eos_id] + self.vocab.text_tokens + [self.vocab.begin_image], dtype=torch.int64, device=dev)
         self.codes_size = vq_cfg.codes_size
         self.image_size = vq_cfg.resolution
         self.dim_z = vq_cfg.z_channels
@@ -123,6 +125,8 @@ class ChameleonARMMWrapper(AutoregressiveMultimodalModelWrapper):
         return self._vq_engine
 
     def set_watermarker(self, watermarker=None, watermarker_text=None):
+        if watermarker is not None and getattr(getattr(watermarker, "seed_strategy", None), "value", None) == "spatial":
+            raise ValueError("Chameleon supports fixed / linear seeding only (the reference's generate.py asserts the same)")
         self.watermarker = watermarker
         self.watermarker_text = watermarker_text
 
@@ -162,6 +166,143 @@ class ChameleonARMMWrapper(AutoregressiveMultimodalModelWrapper):
         unc = [[v.bos_id, v.begin_image] for _ in full]
         return full + img + unc
 
+
+    # ------------------------------------------------------------------ interleaved text + image mode
+    @staticmethod
+    def split_token_sequence(tokens: torch.LongTensor, boi: int, eoi: int):
+        """wmar/models/chameleon_wrapper.py:47-104: cut ONE generated sequence [1, n] into ("text_seg" | "image_seg", tokens [1, m])
+        pieces at the begin-of-image / end-of-image markers (the markers themselves are dropped)."""
+        batch_size, _ = tokens.shape
+        assert batch_size == 1, "Batch size must be 1"
+        device, dtype = tokens.device, tokens.dtype
+        segments, current, in_image = [], [], False
+
+        def flush(kind):
+            segments.append((kind, torch.tensor(current, dtype=dtype, device=device).reshape(1, -1)))
+
+        for token in tokens[0].tolist():
+            if token == boi:
+                if current:
+                    flush("text_seg")
+                    current = []
+                in_image = True
+            elif token == eoi and in_image:
+                flush("image_seg")
+                current = []
+                in_image = False
+            else:
+                current.append(token)
+        if current:
+            flush("image_seg" if in_image else "text_seg")
+        return segments
+
+    def text_logits_chain(self, input_ids: torch.Tensor, logits: torch.Tensor, q: torch.Tensor, *, temperature: float = 0.7,
+                          top_p: float = 0.9, repetition_penalty: float = 1.2, boi_limit: Optional[int] = None,
+                          apply_watermark: bool = False, allowed: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One text-mode step of TextDecoder (chameleon.py:262-284 + generation.py:84-93) on the device: text watermark (called
+        positionally on the padded input rows) -> allow-only (eos + text tokens + <boi>) -> <boi> forbidden at or after
+        `boi_limit` (max_seq_len - 1026) -> HF RepetitionPenaltyLogitsProcessor over the input rows -> /temperature -> top-p ->
+        softmax -> multinomial as argmax(p / q).  input_ids int64 [B, t]; logits float32 [B, V] (modified in place); q [B, V]."""
+        import ctypes as C
+        from .. import _lib
+        dev = self.model.device
+        B, V = logits.shape
+        if apply_watermark and self.watermarker_text is not None:
+            logits = self.watermarker_text.spawn_logit_processor()(input_ids, logits)
+        if allowed is None:
+            allowed = self._allow_text
+        mask = torch.ones(V, dtype=torch.bool, device=dev)
+        mask[allowed] = False
+        logits.masked_fill_(mask[None, :], float("-inf"))
+        if boi_limit is not None and input_ids.shape[1] >= boi_limit:
+            logits[:, self.vocab.begin_image] = float("-inf")
+        if repetition_penalty != 1.0:
+            score = torch.gather(logits, 1, input_ids)
+            score = torch.where(score < 0, score * repetition_penalty, score / repetition_penalty)
+            logits.scatter_(1, input_ids, score)
+        tok = torch.empty(B, dtype=torch.int64, device=dev)
+        scratch = torch.empty_like(logits)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().wmar_sample_fused(None, logits.data_ptr(), B, V, None, 0, 0, float(temperature), 0,
+                                                     float(top_p) if top_p is not None else -1.0, q.contiguous().data_ptr(),
+                                                     scratch.data_ptr(), tok.data_ptr(), _lib.stream_ptr(dev)))
+        return tok
+
+    def _prefill(self, rows: List[List[int]]) -> torch.Tensor:
+        """Right-aligned prefill (alignment.py:27-41 as the model adapter consumes it): logits of the last prompt position."""
+        maxlen = max(len(r) for r in rows)
+        lg = None
+        for j in range(maxlen):
+            tok = [r[j - (maxlen - len(r))] if j - (maxlen - len(r)) >= 0 else 0 for r in rows]
+            pos = [max(j - (maxlen - len(r)), 0) for r in rows]
+            lg = self.model.engine.forward_tokens(torch.tensor(tok, device=self.model.device),
+                                                  torch.tensor(pos, dtype=torch.int32, device=self.model.device), want_logits=j == maxlen - 1)
+        return lg
+
+    # conditioning: list of (index, prompt) tuples; returns the segments of the ONE generated sequence (reference: batch 1)
+    def sample_interleaved(self, conditioning, gen_params, apply_watermark=False, max_gen_len: int = 4096,
+                           text_temperature: float = 0.7, text_top_p: float = 0.9, repetition_penalty: float = 1.2):
+        """wmar/models/chameleon_wrapper.py:108-134 -> Generator with Options(txt=True) (chameleon.py:392-440): text tokens are
+        decoded until every row emits <boi>, then 1024 image tokens under 3-way guidance, <eoi>, text again ... until <eos> or the
+        length limit.  Every switch re-runs the prompt through a fresh decoder, exactly as the reference builds a new
+        TextDecoder / ImageDecoder on the grown input.  The image phases are the captured engine loop; the text steps are eager
+        (one engine forward + the text chain per token)."""
+        v = self.vocab
+        eng = self.model.engine
+        rows = []
+        for _, prompt in conditioning:
+            item = {"type": "text", "value": prompt} if isinstance(prompt, str) else {"type": "ids", "value": prompt}
+            rows.append(self.tokens_from_ui([item, {"type": "sentinel", "value": "<END-OF-TURN>"}]))
+        B = len(rows)
+        if self.seed is not None:
+            torch.manual_seed(self.seed)
+        max_seq_len = eng.max_seq_len
+        generated: List[List[int]] = [[] for _ in range(B)]
+        V = self.model.cfg.vocab_size
+        wm_ctx = self.watermarker.wm_ctx() if (apply_watermark and self.watermarker is not None) else None
+        done = False
+        while not done:
+            # ---------------- text decoder on the current inputs
+            inputs = [r + g for r, g in zip(rows, generated)]
+            max_prompt_len = max(len(r) for r in inputs)
+            limit = min(max_seq_len, max_prompt_len + max_gen_len)
+            padded = torch.tensor([[v.pad_id] * (max_prompt_len - len(r)) + r for r in inputs], dtype=torch.int64, device=self.model.device)
+            lens = torch.tensor([len(r) for r in inputs], dtype=torch.int32, device=self.model.device)
+            lg = self._prefill(inputs)
+            switch = False
+            n_new = 0
+            while True:
+                # stopping criteria of the TextDecoder (chameleon.py:232-236): length, or <eos> in every row after the prompt
+                if padded.shape[1] >= limit or bool((padded[:, max_prompt_len:] == v.eos_id).any(dim=1).all()):
+                    done = True
+                    break
+                q = self._noise_draw(lambda t, g: t.exponential_(1, generator=g), (B, V))
+                tok = self.text_logits_chain(padded, lg, q, temperature=text_temperature, top_p=text_top_p,
+                                             repetition_penalty=repetition_penalty, boi_limit=max_seq_len - (self.n_image_tokens + 2),   # max_seq_len - 1026 at 1024 image tokens (chameleon.py:271-275)
+                                             apply_watermark=apply_watermark)
+                padded = torch.cat([padded, tok[:, None]], dim=1)
+                for b, t in enumerate(tok.tolist()):
+                    generated[b].append(t)
+                n_new += 1
+                if bool((tok == v.begin_image).all()):
+                    switch = True
+                    break
+                lg = eng.forward_tokens(tok, lens + (n_new - 1))
+            if done or not switch:
+                break
+            # ---------------- image decoder: 1024 tokens, then <eoi> (chameleon.py:374-389)
+            inputs = [r + g for r, g in zip(rows, generated)]
+            if max(len(r) for r in inputs) + self.n_image_tokens > max_seq_len:
+                break
+            q = self.draw_noise(B)
+            img = eng.generate_image(self.split_inputs_for_cfg(inputs), q, self.n_image_tokens, gen_params["temperature"], gen_params["top_p"],
+                                     self.guidance_scale_text, self.guidance_scale_image, allow=self._allow_img, wm_ctx=wm_ctx,
+                                     use_graph=self.use_graph, allow_ids=self._allow_ids, pad_id=v.pad_id)
+            for b in range(B):
+                generated[b] += img[b].tolist() + [v.end_image]
+        codes = torch.tensor(generated, dtype=torch.int64, device=self.model.device).contiguous()
+        return self.split_token_sequence(codes, v.begin_image, v.end_image)
+
     def draw_noise(self, B: int, generator=None) -> torch.Tensor:
         """One [B, V] Exp(1) draw per image token: what ``probs.multinomial`` on the first stream consumes (token_selector.py:26-47)."""
         V = self.model.cfg.vocab_size
@@ -189,7 +330,7 @@ class ChameleonARMMWrapper(AutoregressiveMultimodalModelWrapper):
             out[b0:b1] = self.model.engine.generate_image(
                 self.split_inputs_for_cfg(prompts[b0:b1]), qq, self.n_image_tokens, gen_params["temperature"], gen_params["top_p"],
                 self.guidance_scale_text, self.guidance_scale_image, allow=self._allow_img, wm_ctx=wm_ctx, use_graph=self.use_graph,
-                allow_ids=self._allow_ids)
+                allow_ids=self._allow_ids, pad_id=self.vocab.pad_id)
         codes = out.detach().contiguous()
         assert self.is_codes_shaped(codes), f"Codes shape: {codes.shape}"
         return codes

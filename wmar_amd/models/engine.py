@@ -384,10 +384,11 @@ class ChameleonEngine:
     def generate_image(self, prompts, q: torch.Tensor, n_tokens: int, temperature: float, top_p: Optional[float],
                        guidance_scale_text: float, guidance_scale_image: float, allow: Optional[torch.Tensor] = None,
                        wm_ctx: Optional[_lib.WmCtx] = None, use_graph: bool = True,
-                       allow_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       allow_ids: Optional[torch.Tensor] = None, pad_id: int = 1) -> torch.Tensor:
         """prompts: the 3B token lists (full-, image-, un-conditioned, in that order); q float32 [n_tokens, B, V];
         allow: int32 bitmap [V/32] of permitted vocabulary entries; allow_ids: the same set as ascending int32 ids (lets the
-        sampler work on the compacted row).  Returns int64 [B, n_tokens] vocabulary ids."""
+        sampler work on the compacted row); pad_id: the id short prompts are left-padded with (it can enter the watermark context
+        of the first image tokens).  Returns int64 [B, n_tokens] vocabulary ids."""
         _require_cuda(q, "q")
         M = len(prompts)
         assert M % 3 == 0
@@ -398,7 +399,7 @@ class ChameleonEngine:
         lens = np.ascontiguousarray(np.asarray([len(p) for p in prompts], dtype=np.int32))
         out = torch.empty(B, n_tokens, dtype=torch.int64, device=self.device)
         sp = _lib.ChamSampleParams(float(temperature), float(top_p) if top_p is not None else -1.0, float(guidance_scale_text),
-                                   float(guidance_scale_image), 1 if use_graph else 0)
+                                   float(guidance_scale_image), 1 if use_graph else 0, int(pad_id))
         if allow is not None:
             _require_cuda(allow, "allow bitmap")
             assert allow.dtype == torch.int32 and allow.numel() == V // 32 and allow.is_contiguous()

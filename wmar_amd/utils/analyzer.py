@@ -51,3 +51,40 @@ def summarize(records: List[dict], fpr: float = 0.01) -> Dict[str, dict]:
             "log10_p_median": float(np.median(np.log10(np.maximum(finite, 1e-300)))) if finite else None,
         }
     return out
+
+
+def load_results_dir(root: str, resultdir_prefix: str, method_id: str) -> Tuple[Dict[str, list], Dict[str, list], int]:
+    """``Analyzer.get_metrics_imagepaths_N`` (wmar/utils/analyzer.py:186-238) for one method: walk
+    ``root/<dirs starting with resultdir_prefix>/c=<class>,idx=<n>/`` as generate.py writes them (generate.py:79-108), collect the
+    metric jsons named ``<idx>_<method>_<transform>_<param>.json`` into ``{"<transform>_<param>": [metrics, ...]}`` and the
+    ``roundtrips_0`` PNG paths per class.  Returns (all_metrics, all_orig_image_paths, N = number of result directories)."""
+    import json
+    import os
+
+    dirs = [d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d)) and d.startswith(resultdir_prefix)]
+    result_dirs = []
+    for d in dirs:
+        result_dirs += [os.path.join(root, d, s) for s in os.listdir(os.path.join(root, d)) if os.path.isdir(os.path.join(root, d, s))]
+    all_metrics: Dict[str, list] = {}
+    all_orig: Dict[str, list] = {}
+    for rd in result_dirs:
+        toks = [t.split("=")[-1] for t in os.path.basename(rd).split(",")]
+        cls = toks[0]
+        for base, _, files in os.walk(rd):
+            for f in files:
+                stem, ext = os.path.splitext(f)
+                parts = stem.split("_")
+                if len(parts) != 4 or parts[1] != method_id:
+                    continue
+                _, _, aug, param = parts
+                if ext == ".json":
+                    with open(os.path.join(base, f)) as fh:
+                        all_metrics.setdefault(f"{aug}_{param}", []).append(json.load(fh))
+                elif ext == ".png" and aug == "roundtrips" and param == "0":
+                    all_orig.setdefault(cls, []).append(os.path.join(base, f))
+    return all_metrics, all_orig, len(result_dirs)
+
+
+def tpr_table(all_metrics: Dict[str, list], fpr: float = 0.01) -> Dict[str, float]:
+    """TPR at `fpr` per "<transform>_<param>" of a ``load_results_dir`` dictionary (the rule of plot_robustness)."""
+    return {k: tpr_at_fpr([m.get("pvalue") for m in v], fpr) for k, v in sorted(all_metrics.items())}
