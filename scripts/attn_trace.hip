@@ -27,7 +27,7 @@ int main(int argc, char** argv) {
     const int nwg = B * H;
     hipMalloc(&tr, (size_t)nwg * 5 * 8);
     AttnArgs t{};
-    t.qkv_slabs = pieces; t.slab_stride = (long long)act3; t.S = S; t.stats = stats; t.n_chunks = S; t.K = D; t.c1 = c1; t.bias = bias;
+    t.qkv_slabs = pieces; t.slab_stride = (long long)act3; t.S = S; t.stats = stats; t.n_chunks = S; t.K = D; t.invK = 1.0 / (double)D; t.c1 = c1; t.bias = bias;
     t.y = y; t.pos_dev = pos; t.D = D; t.H = H; t.Tmax = Tmax; t.MT = MT; t.scale = 0.125f; t.trace = tr;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {

@@ -768,6 +768,7 @@ struct AttnArgs {
     long long slab_stride;     // float4 units
     int S;
     const double* stats; int n_chunks; int K;   // LN1 row statistics (see k_resid_stats)
+    double invK;               // 1 / K (host-computed: a double division costs the prologue ~100 cycles)
     const float* c1;           // [3D] row sums of the gamma-folded QKV weights (mode 0)
     const float* bias;         // [3D] bias (+ W beta in mode 0)
     int mode;                  // 0: minGPT (LN1 folded, finish with LN algebra); 1: RAR (plain bias, then per-head
@@ -828,7 +829,9 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
     tr[0] = __builtin_amdgcn_s_memtime();
 #endif
     // PF2: the wave's first TWO chunks are requested before the prologue (32 KiB in flight per wave: with 1 / 2 / 4 waves the
-    // whole cache up to 64 / 128 / 256 rows streams while q/k/v are finished); otherwise one, the second from inside the loop
+    // whole cache up to 64 / 128 / 256 rows streams while q/k/v are finished); otherwise one, the second from inside the loop.
+    // (Measured dead end: clamping the first chunk to the cache's capacity instead of its fill, so that its loads need not wait
+    // for the scalar load of the position, saves 1.3 us at 64 rows and costs 3 us below 32 rows -- stale rows are then streamed.)
     if (w < nchunk) { WMAR_ATT_LOAD(kA, vA, w) }
     if (PF2 && w + NWA < nchunk) { WMAR_ATT_LOAD(kB, vB, w + NWA) }
     __builtin_amdgcn_sched_barrier(0);
@@ -874,7 +877,7 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
-        const double invK = 1.0 / (double)a.K;
+        const double invK = a.invK;
         const double mean = sm * invK;
         const float mu = (float)mean;
         const float rstd = rsqrtf((float)(sq * invK - mean * mean) + 1e-5f);

@@ -253,7 +253,7 @@ struct StepPlan {
         const LayerW& w = g->layers[l];
         const long long lstride = (long long)g->Bmax * g->H * g->Tmax * g->hd;
         AttnArgs t{};
-        t.qkv_slabs = g->qkv_slabs; t.slab_stride = 3 * act; t.K = D;
+        t.qkv_slabs = g->qkv_slabs; t.slab_stride = 3 * act; t.K = D; t.invK = 1.0 / (double)D;
         if (S_qx > 0) { t.S = S_qx; t.stats = g->stats_q; t.n_chunks = S_qx; }
         else { t.S = S_qkv; t.stats = g->stats; t.n_chunks = nch; }
         t.c1 = w.cqkv; t.bias = w.bqkv;

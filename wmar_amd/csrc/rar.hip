@@ -299,7 +299,7 @@ struct RarPlan {
         if ((rc = gemm_split(a, &S, st, 1))) return rc;
         AttnArgs t{};
         const long long lstride = (long long)g->Mmax * g->H * g->T * g->hd;
-        t.qkv_slabs = g->qkv_slabs; t.slab_stride = 3 * act; t.S = 1; t.stats = g->stats; t.n_chunks = nch; t.K = D;
+        t.qkv_slabs = g->qkv_slabs; t.slab_stride = 3 * act; t.S = 1; t.stats = g->stats; t.n_chunks = nch; t.K = D; t.invK = 1.0 / (double)D;
         t.bias = w.bqkv; t.mode = 1; t.qn_w = w.qnw; t.qn_b = w.qnb; t.kn_w = w.knw; t.kn_b = w.knb;
         t.kcache = g->kcache + l * lstride; t.vcache = g->vcache + l * lstride; t.y = g->y; t.pos_dev = g->ctr;
         t.D = D; t.H = g->H; t.Tmax = g->T; t.MT = MT; t.scale = 1.0f / sqrtf((float)g->hd);
