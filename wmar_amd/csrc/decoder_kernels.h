@@ -16,6 +16,12 @@ __device__ __forceinline__ float4 ld_nt(const float4* p) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ float2 ld_nt2(const float2* p) {
+    f32x2 v = __builtin_nontemporal_load((const f32x2*)p);
+    return make_float2(v.x, v.y);
+}
+
 constexpr int MAX_SLABS = 8;
 constexpr int QKV_SLABS_MAX = 8;   // the QKV projection arrives in at most 8 split-K pieces
 constexpr int STAT_CHUNKS_MAX = 64;   // n_embd <= 8192
@@ -470,6 +476,219 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
         }
     }
 #ifdef WMAR_GEMM_TRACE
+    if (a.trace && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* t = a.trace + (long long)blockIdx.x * 4;
+        t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = __builtin_amdgcn_s_memtime();
+    }
+#endif
+}
+
+// --------------------------------------------------------- FC1 (+ LayerNorm algebra + GELU) on 24-column tiles
+// The GELU needs complete sums, so FC1 cannot be split over K across workgroups; with 32-column tiles its 6144 columns make 192
+// workgroups and a quarter of the CUs idle.  6144 = 256 x 24: a workgroup of this kernel owns 24 columns x all 64 rows and
+// the chip is full.  24 columns are formed at the full fp32 MFMA rate from two multi-block instructions that share ONE B
+// operand (the 64 rows of one k: lane = row):
+//     v_mfma_f32_16x16x1_4b_f32   4 blocks = 4 row tiles of 16, A (16 columns) broadcast from block k%4     32 cycles
+//     v_mfma_f32_4x4x1_16b_f32   16 blocks = 16 row tiles of 4,  A (4 columns) broadcast from block k%16     8 cycles, twice
+// = 48 cycles per k for 24 x 64 outputs (measured 49.5) against 64 cycles per k for 32 x 64 with v_mfma_f32_32x32x2_f32.
+// The packed activation holds a k-block as float4 (4 consecutive k of a row; lanes >= 32 carry k+4..k+7): one
+// v_permlane32_swap per component turns the two row tiles into "row = lane" operands for k and k+4.  The K walk visits
+// k, k+4, k+1, k+5, ... inside a k-block -- the order v_mfma_f32_32x32x2_f32 applies its two k -- so a tile's fp32 summation
+// chain is the one k_gemm produces.  Four waves split K and meet in LDS (fixed order), as in k_gemm.
+#ifndef FX_ABL
+#define FX_ABL 0     // dev ablations: 1 = no loads in the main loop, 2 = no lane swaps, 4 = no 4x4 MFMAs
+#endif
+struct Fc1xArgs {
+    const float4* W16;         // [N/24][K/16][64]: lane = 16*(k%4) + col, component q <-> k = 16*kk + 4*q + k%4, cols 0..15 of the tile
+    const float2* W8;          // [N/24][K/16][64]: lane = 4*(k%16) + col%4, component g <-> cols 16+4g .. 19+4g
+    const float4* Xp;          // packed [K/8][2][64]
+    const float* bias;         // [N] bias + W beta (LN folded)
+    const float* c1;           // [N] row sums of the gamma-folded weights
+    const double* stats; int n_chunks; int K;
+    float4* out;               // packed hidden activation [N/8][2][64]
+    int KU;                    // K / 16
+    unsigned long long* trace; // dev only (WMAR_FX_TRACE): 4 timestamps per workgroup
+};
+
+static __global__ void k_pack_fc1x(const float* __restrict__ W, const float* __restrict__ gamma, float4* __restrict__ W16,
+                                   float2* __restrict__ W8, int N, int K) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over (N/24) * (K/16) * 64
+    const int KU = K / 16;
+    if (idx >= (long long)(N / 24) * KU * 64) return;
+    const int lane = (int)(idx & 63);
+    const long long r = idx >> 6;
+    const int kk = (int)(r % KU), tile = (int)(r / KU);
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = tile * 24 + (lane & 15), k = kk * 16 + 4 * q + (lane >> 4);
+        v[q] = W[(long long)n * K + k] * (gamma ? gamma[k] : 1.f);
+    }
+    W16[idx] = make_float4(v[0], v[1], v[2], v[3]);
+    float u[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int n = tile * 24 + 16 + 4 * g + (lane & 3), k = kk * 16 + (lane >> 2);
+        u[g] = W[(long long)n * K + k] * (gamma ? gamma[k] : 1.f);
+    }
+    W8[idx] = make_float2(u[0], u[1]);
+}
+
+static __global__ __launch_bounds__(256) void k_fc1x(Fc1xArgs a) {
+    __shared__ __attribute__((aligned(16))) float4 red[4][6][64];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x;
+    // K units (16 k) of this wave; the walk starts at a tile-dependent unit and wraps (all workgroups read the SAME activation
+    // rows: started in lockstep they would queue on the same L2 channels)
+    const int per = a.KU >> 2;                 // host: KU % 16 == 0
+    const int u0 = w * per;
+    const int rot = (tile * 5) % per;
+#define WMAR_FX_UNIT(I) (u0 + (((I) + rot) >= per ? (I) + rot - per : (I) + rot))
+
+    f32x16 acc16;
+    f32x4 acc4a, acc4b;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc16[r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { acc4a[r] = 0.f; acc4b[r] = 0.f; }
+
+    const float4* W16 = a.W16 + (long long)tile * a.KU * 64 + lane;
+    const float2* W8 = a.W8 + (long long)tile * a.KU * 64 + lane;
+    const float4* Xp = a.Xp + lane;
+    // four-unit register ring: the loads of unit i+3 are issued (one per k-pair) while unit i is multiplied -- three units
+    // (~1.7 us) of distance, above the loaded HBM latency; one unit of distance measured 45 % slower
+    float4 xA[2][2], xB[2][2], xC[2][2], xD[2][2], wqA, wqB, wqC, wqD;
+    float2 w8A, w8B, w8C, w8D;
+#define WMAR_FX_LOAD(XB, WQ, W8V, UNIT)                                                          \
+    {                                                                                             \
+        const int un = (UNIT);                                                                    \
+        WQ = ld_nt(W16 + (long long)un * 64);                                                     \
+        W8V = ld_nt2(W8 + (long long)un * 64);                                                    \
+        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                          \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                         \
+                XB[kb][i] = Xp[((long long)(un * 2 + kb) * 2 + i) * 64];                          \
+    }
+// the 16 k of a unit in the order 0,4,1,5,2,6,3,7 | 8,12,9,13,...: component j of k-block kb holds k = 8*kb + j (+4 in the upper lanes)
+// One unit (16 k = 48 MFMAs).  Everything else a wave has to issue rides in the shadow of the MFMAs, one item per k-pair,
+// because the wave issues in order and anything in front of a dependent MFMA idles the matrix pipe:
+//   * the six loads of the unit three ahead (XL / WQL / W8L <- UNITL);
+//   * the eight lane swaps that turn the NEXT unit's packed k-blocks (XS) into "row = lane" operands (BN): a swap right before
+//     the MFMA that consumes it costs ~21 cycles of pipe idle (measured), a whole unit earlier it costs nothing.
+#define WMAR_FX_SWAP(BDST, XS, SLOT)                                                             \
+    {                                                                                             \
+        const int kb_ = (SLOT) >> 2, j_ = (SLOT) & 3;                                             \
+        const float c0 = j_ == 0 ? XS[kb_][0].x : (j_ == 1 ? XS[kb_][0].y : (j_ == 2 ? XS[kb_][0].z : XS[kb_][0].w)); \
+        const float c1 = j_ == 0 ? XS[kb_][1].x : (j_ == 1 ? XS[kb_][1].y : (j_ == 2 ? XS[kb_][1].z : XS[kb_][1].w)); \
+        if (FX_ABL & 2) { BDST[SLOT][0] = c0; BDST[SLOT][1] = c1; }                               \
+        else {                                                                                    \
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(c0), __float_as_uint(c1), false, false); \
+            BDST[SLOT][0] = __uint_as_float(sw[0]); BDST[SLOT][1] = __uint_as_float(sw[1]);       \
+        }                                                                                         \
+    }
+#define WMAR_FX_MMA(BC, WQ, W8V, BN, XS, XL, WQL, W8L, UNITL)                                    \
+    {                                                                                             \
+        const int un_ = (UNITL);                                                                  \
+        _Pragma("unroll") for (int slot = 0; slot < 8; ++slot) {                                  \
+            const int kb = slot >> 2, j = slot & 3;                                               \
+            /* k16 = 8*kb + j (register q = 2*kb, block j) and k16 + 4 (register q = 2*kb + 1, block j) */ \
+            const float aq0 = kb == 0 ? WQ.x : WQ.z, aq1 = kb == 0 ? WQ.y : WQ.w;                 \
+            /* every non-MFMA instruction directly behind a 16x16 MFMA: it issues inside that instruction's 32 cycles */ \
+            fx16(acc16, BC[slot][0], aq0, j);                                                     \
+            WMAR_FX_SWAP(BN, XS, slot)                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+            fx4(acc4a, acc4b, BC[slot][0], W8V, 8 * kb + j);                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+            fx16(acc16, BC[slot][1], aq1, j);                                                     \
+            if (!(FX_ABL & 1)) {                                                                  \
+                if (slot == 0) WQL = ld_nt(W16 + (long long)un_ * 64);                            \
+                if (slot == 1) W8L = ld_nt2(W8 + (long long)un_ * 64);                            \
+                if (slot >= 2 && slot < 6)                                                        \
+                    XL[(slot - 2) >> 1][(slot - 2) & 1] = Xp[((long long)(un_ * 2 + ((slot - 2) >> 1)) * 2 + ((slot - 2) & 1)) * 64]; \
+            }                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+            fx4(acc4a, acc4b, BC[slot][1], W8V, 8 * kb + 4 + j);                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+        }                                                                                         \
+    }
+    // (the block / k16 immediates need compile-time constants: dispatch through a switch on unrolled indices)
+    auto fx16 = [&](f32x16& c16, float bv, float aq, int j) {          // the 32-cycle instruction: block j of the A register
+        if (j == 0) c16 = __builtin_amdgcn_mfma_f32_16x16x1f32(aq, bv, c16, 2, 0, 0);
+        if (j == 1) c16 = __builtin_amdgcn_mfma_f32_16x16x1f32(aq, bv, c16, 2, 1, 0);
+        if (j == 2) c16 = __builtin_amdgcn_mfma_f32_16x16x1f32(aq, bv, c16, 2, 2, 0);
+        if (j == 3) c16 = __builtin_amdgcn_mfma_f32_16x16x1f32(aq, bv, c16, 2, 3, 0);
+    };
+    auto fx4 = [&](f32x4& c4a, f32x4& c4b, float bv, const float2& w8v, int k16) {     // the two 8-cycle instructions: block k16
+        if (FX_ABL & 4) return;
+#define WMAR_FX_CASE(KV)                                                                          \
+        if (k16 == KV) {                                                                          \
+            c4a = __builtin_amdgcn_mfma_f32_4x4x1f32(w8v.x, bv, c4a, 4, KV, 0);                   \
+            c4b = __builtin_amdgcn_mfma_f32_4x4x1f32(w8v.y, bv, c4b, 4, KV, 0);                   \
+        }
+        WMAR_FX_CASE(0) WMAR_FX_CASE(1) WMAR_FX_CASE(2) WMAR_FX_CASE(3) WMAR_FX_CASE(4) WMAR_FX_CASE(5) WMAR_FX_CASE(6) WMAR_FX_CASE(7)
+        WMAR_FX_CASE(8) WMAR_FX_CASE(9) WMAR_FX_CASE(10) WMAR_FX_CASE(11) WMAR_FX_CASE(12) WMAR_FX_CASE(13) WMAR_FX_CASE(14) WMAR_FX_CASE(15)
+#undef WMAR_FX_CASE
+    };
+
+#ifdef WMAR_FX_TRACE
+    const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
+#endif
+    WMAR_FX_LOAD(xA, wqA, w8A, WMAR_FX_UNIT(0))
+    WMAR_FX_LOAD(xB, wqB, w8B, WMAR_FX_UNIT(1))
+    WMAR_FX_LOAD(xC, wqC, w8C, WMAR_FX_UNIT(2))
+    __builtin_amdgcn_sched_barrier(0);
+    float mu, rstd;       // LayerNorm statistics of row = lane, fetched behind the first operands
+    ln_row_stats(a.stats, a.n_chunks, 64, lane, a.K, &mu, &rstd);
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef WMAR_FX_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tr1 = __builtin_amdgcn_s_memtime();
+#endif
+#define WMAR_FX_NEXT(I) WMAR_FX_UNIT((I) < per ? (I) : (I) - per)     /* past the end: an in-bounds re-read instead of a branch */
+    float bA[8][2], bB[8][2];
+#pragma unroll
+    for (int slot = 0; slot < 8; ++slot) WMAR_FX_SWAP(bA, xA, slot)
+    for (int it = 0; it < per; it += 4) {
+        WMAR_FX_MMA(bA, wqA, w8A, bB, xB, xD, wqD, w8D, WMAR_FX_NEXT(it + 3))
+        WMAR_FX_MMA(bB, wqB, w8B, bA, xC, xA, wqA, w8A, WMAR_FX_NEXT(it + 4))
+        WMAR_FX_MMA(bA, wqC, w8C, bB, xD, xB, wqB, w8B, WMAR_FX_NEXT(it + 5))
+        WMAR_FX_MMA(bB, wqD, w8D, bA, xA, xC, wqC, w8C, WMAR_FX_NEXT(it + 6))
+    }
+#undef WMAR_FX_NEXT
+#undef WMAR_FX_LOAD
+#undef WMAR_FX_MMA
+#undef WMAR_FX_SWAP
+#undef WMAR_FX_UNIT
+
+#ifdef WMAR_FX_TRACE
+    const unsigned long long tr2 = __builtin_amdgcn_s_memtime();
+#endif
+    // cross-wave K reduction in LDS (fixed order), LayerNorm algebra, bias, GELU, packed store
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        red[w][b][lane] = make_float4(acc16[4 * b + 0], acc16[4 * b + 1], acc16[4 * b + 2], acc16[4 * b + 3]);
+    red[w][4][lane] = make_float4(acc4a[0], acc4a[1], acc4a[2], acc4a[3]);
+    red[w][5][lane] = make_float4(acc4b[0], acc4b[1], acc4b[2], acc4b[3]);
+    __syncthreads();
+    for (int gi = w; gi < 6; gi += 4) {
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const float4 t = red[ww][gi][lane];
+            o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
+        }
+        // accumulator layouts: 16x16 block b = gi: columns 4*(lane/16) .. +3 of row 16*b + lane%16;  4x4: columns 16 + 4*(gi-4) .. +3 of row lane
+        const int m = gi < 4 ? 16 * gi + (lane & 15) : lane;
+        const int n = tile * 24 + (gi < 4 ? 4 * (lane >> 4) : 16 + 4 * (gi - 4));
+        const float mm = __shfl(mu, m), rs = __shfl(rstd, m);
+        const float4 cc = *(const float4*)(a.c1 + n);
+        const float4 bb = *(const float4*)(a.bias + n);
+        o[0] = gelu_erf(rs * (o[0] - mm * cc.x) + bb.x); o[1] = gelu_erf(rs * (o[1] - mm * cc.y) + bb.y);
+        o[2] = gelu_erf(rs * (o[2] - mm * cc.z) + bb.z); o[3] = gelu_erf(rs * (o[3] - mm * cc.w) + bb.w);
+        a.out[((long long)(n >> 3) * 2 + (m >> 5)) * 64 + (m & 31) + 32 * ((n >> 2) & 1)] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+#ifdef WMAR_FX_TRACE
     if (a.trace && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned long long* t = a.trace + (long long)blockIdx.x * 4;

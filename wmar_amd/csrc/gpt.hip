@@ -29,6 +29,8 @@ using namespace wmar;
 // ------------------------------------------------------------------------------ engine
 struct LayerW {
     float4 *wqkv, *wproj, *wfc1, *wfc2;
+    float4* wfc1x16 = nullptr;   // FC1 in k_fc1x's 24-column packing (null: shape not eligible)
+    float2* wfc1x8 = nullptr;
     float *bqkv, *bproj, *bfc1, *bfc2, *cqkv, *cfc1;
 };
 
@@ -298,7 +300,16 @@ struct StepPlan {
         f.Wp = w.wfc1; f.Xp = xcur; f.bias = w.bfc1; f.c1 = w.cfc1; f.KB = KBD; f.NT = 4 * D / 32;
         f.out_packed = g->hbuf; f.slab_stride = 0;
         g->span_begin(WMAR_T_FC1, st);
-        int rc = gemm_dispatch<EPI_GELU, true>(f, false, st);
+        int rc;
+        if (MT == 2 && w.wfc1x16) {
+            Fc1xArgs x{};
+            x.W16 = w.wfc1x16; x.W8 = w.wfc1x8; x.Xp = xcur; x.bias = w.bfc1; x.c1 = w.cfc1; x.stats = g->stats; x.n_chunks = nch; x.K = D;
+            x.out = g->hbuf; x.KU = D / 16;
+            hipLaunchKernelGGL(k_fc1x, dim3((unsigned)(4 * D / 24)), dim3(256), 0, st, x);
+            rc = launch_status("k_fc1x");
+        } else {
+            rc = gemm_dispatch<EPI_GELU, true>(f, false, st);
+        }
         g->span_end(st);
         return rc;
     }
@@ -436,6 +447,17 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
         TRY(copy_vec(g, &w.bproj, pb, D, st));
         TRY(g->alloc(&w.wfc1, (size_t)4 * D * D / 4));
         TRY(pack(f1w, w.wfc1, 4 * D, D, 0, st, l2w));
+        if ((4 * D) % 24 == 0 && (D / 16) % 16 == 0 && g->MTmax >= 2) {
+            // batches of 33..64 rows run FC1 on 24-column tiles (k_fc1x: one workgroup per CU at n_embd 1536); the 32-column
+            // packing above serves the other batch sizes
+            const size_t units = (size_t)(4 * D / 24) * (D / 16) * 64;
+            TRY(g->alloc(&w.wfc1x16, units));
+            TRY(g->alloc(&w.wfc1x8, units));
+            if (rc == WMAR_OK) {
+                hipLaunchKernelGGL(k_pack_fc1x, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, f1w, l2w, w.wfc1x16, w.wfc1x8, 4 * D, D);
+                rc = launch_status("k_pack_fc1x");
+            }
+        }
         TRY(g->alloc(&w.bfc1, (size_t)4 * D));
         TRY(fold_bias(f1w, f1b, l2b, w.bfc1, 4 * D, D, st));
         TRY(g->alloc(&w.cfc1, (size_t)4 * D));
