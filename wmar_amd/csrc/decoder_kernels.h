@@ -487,21 +487,24 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
 // --------------------------------------------------------- FC1 (+ LayerNorm algebra + GELU) on 24-column tiles
 // The GELU needs complete sums, so FC1 cannot be split over K across workgroups; with 32-column tiles its 6144 columns make 192
 // workgroups and a quarter of the CUs idle.  6144 = 256 x 24: a workgroup of this kernel owns 24 columns x all 64 rows and
-// the chip is full.  24 columns are formed at the full fp32 MFMA rate from two multi-block instructions that share ONE B
-// operand (the 64 rows of one k: lane = row):
-//     v_mfma_f32_16x16x1_4b_f32   4 blocks = 4 row tiles of 16, A (16 columns) broadcast from block k%4     32 cycles
-//     v_mfma_f32_4x4x1_16b_f32   16 blocks = 16 row tiles of 4,  A (4 columns) broadcast from block k%16     8 cycles, twice
-// = 48 cycles per k for 24 x 64 outputs (measured 49.5) against 64 cycles per k for 32 x 64 with v_mfma_f32_32x32x2_f32.
-// The packed activation holds a k-block as float4 (4 consecutive k of a row; lanes >= 32 carry k+4..k+7): one
-// v_permlane32_swap per component turns the two row tiles into "row = lane" operands for k and k+4.  The K walk visits
-// k, k+4, k+1, k+5, ... inside a k-block -- the order v_mfma_f32_32x32x2_f32 applies its two k -- so a tile's fp32 summation
-// chain is the one k_gemm produces.  Four waves split K and meet in LDS (fixed order), as in k_gemm.
+// the chip is full.  24 columns are formed at the full fp32 MFMA rate from two multi-block instructions that take the SAME B
+// register -- one component of the packed activation as it lies in memory (lanes 0..31: rows of a 32-row tile at k, lanes
+// 32..63: the same rows at k+4), no lane shuffles:
+//     v_mfma_f32_16x16x1_4b_f32  blocks {0,1} = rows 0-15 / 16-31 at k, blocks {2,3} = the same rows at k+4; A (16 columns) is
+//                                broadcast within each block PAIR (cbsz 1): lanes 0-31 of the A register carry two k-pairs'
+//                                "k" columns, lanes 32-63 their "k+4" columns, abid picks the pair                32 cycles
+//     v_mfma_f32_4x4x1_16b_f32   blocks 0-7 = 4-row groups at k, 8-15 at k+4; A (4 columns) broadcast within each OCTET (cbsz 3):
+//                                one A register holds all eight k-pairs of a 16-k unit, abid picks the pair       8 cycles, twice
+// = 2 x 48 cycles per k-pair for 24 x 64 outputs against 2 x 64 with v_mfma_f32_32x32x2_f32 on 32 columns.  The "k" and "k+4"
+// partial sums of a row sit in different blocks (16x16: different registers, 4x4: lanes l and l+32) and are added once, after
+// the K loop.  Four waves split K and meet in LDS (fixed order), as in k_gemm.  (First version: operands turned into "row =
+// lane" registers with v_permlane32_swap and one accumulator set -- each swap in front of its MFMA cost ~20 cycles of idle pipe.)
 #ifndef FX_ABL
-#define FX_ABL 0     // dev ablations: 1 = no loads in the main loop, 2 = no lane swaps, 4 = no 4x4 MFMAs
+#define FX_ABL 0     // dev ablations: 1 = no loads in the main loop, 4 = no 4x4 MFMAs
 #endif
 struct Fc1xArgs {
-    const float4* W16;         // [N/24][K/16][64]: lane = 16*(k%4) + col, component q <-> k = 16*kk + 4*q + k%4, cols 0..15 of the tile
-    const float2* W8;          // [N/24][K/16][64]: lane = 4*(k%16) + col%4, component g <-> cols 16+4g .. 19+4g
+    const float4* W16;         // [N/24][K/16][64] x 4 registers: register q, lane 16*blk + col: pair 2q + (blk&1), k or k+4 by blk>>1
+    const float2* W8;          // [N/24][K/16][64] x 2 registers (columns 16-19 / 20-23): lane 4*blk + col: pair blk&7, k or k+4 by blk>>3
     const float4* Xp;          // packed [K/8][2][64]
     const float* bias;         // [N] bias + W beta (LN folded)
     const float* c1;           // [N] row sums of the gamma-folded weights
@@ -511,6 +514,7 @@ struct Fc1xArgs {
     unsigned long long* trace; // dev only (WMAR_FX_TRACE): 4 timestamps per workgroup
 };
 
+// pair p = 4*kb + j of a 16-k unit covers k = 8*kb + j ("lo") and k + 4 ("hi")
 static __global__ void k_pack_fc1x(const float* __restrict__ W, const float* __restrict__ gamma, float4* __restrict__ W16,
                                    float2* __restrict__ W8, int N, int K) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over (N/24) * (K/16) * 64
@@ -522,14 +526,16 @@ static __global__ void k_pack_fc1x(const float* __restrict__ W, const float* __r
     float v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int n = tile * 24 + (lane & 15), k = kk * 16 + 4 * q + (lane >> 4);
+        const int blk = lane >> 4, pair = 2 * q + (blk & 1);
+        const int n = tile * 24 + (lane & 15), k = kk * 16 + 8 * (pair >> 2) + (pair & 3) + 4 * (blk >> 1);
         v[q] = W[(long long)n * K + k] * (gamma ? gamma[k] : 1.f);
     }
     W16[idx] = make_float4(v[0], v[1], v[2], v[3]);
     float u[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const int n = tile * 24 + 16 + 4 * g + (lane & 3), k = kk * 16 + (lane >> 2);
+        const int blk = lane >> 2, pair = blk & 7;
+        const int n = tile * 24 + 16 + 4 * g + (lane & 3), k = kk * 16 + 8 * (pair >> 2) + (pair & 3) + 4 * (blk >> 3);
         u[g] = W[(long long)n * K + k] * (gamma ? gamma[k] : 1.f);
     }
     W8[idx] = make_float2(u[0], u[1]);
@@ -547,18 +553,21 @@ static __global__ __launch_bounds__(256) void k_fc1x(Fc1xArgs a) {
     const int rot = (tile * 5) % per;
 #define WMAR_FX_UNIT(I) (u0 + (((I) + rot) >= per ? (I) + rot - per : (I) + rot))
 
-    f32x16 acc16;
-    f32x4 acc4a, acc4b;
+    f32x16 acc16[2];
+    f32x4 acc4a[2], acc4b[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc16[r] = 0.f;
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { acc4a[r] = 0.f; acc4b[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) acc16[i][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc4a[i][r] = 0.f; acc4b[i][r] = 0.f; }
+    }
 
     const float4* W16 = a.W16 + (long long)tile * a.KU * 64 + lane;
     const float2* W8 = a.W8 + (long long)tile * a.KU * 64 + lane;
     const float4* Xp = a.Xp + lane;
-    // four-unit register ring: the loads of unit i+3 are issued (one per k-pair) while unit i is multiplied -- three units
-    // (~1.7 us) of distance, above the loaded HBM latency; one unit of distance measured 45 % slower
+    // four-unit register ring: the loads of unit i+3 are issued (one per k-pair, each right behind a 32-cycle MFMA) while unit i
+    // is multiplied -- three units (~1.5 us) of distance, above the loaded HBM latency
     float4 xA[2][2], xB[2][2], xC[2][2], xD[2][2], wqA, wqB, wqC, wqD;
     float2 w8A, w8B, w8C, w8D;
 #define WMAR_FX_LOAD(XB, WQ, W8V, UNIT)                                                          \
@@ -570,66 +579,45 @@ static __global__ __launch_bounds__(256) void k_fc1x(Fc1xArgs a) {
             _Pragma("unroll") for (int i = 0; i < 2; ++i)                                         \
                 XB[kb][i] = Xp[((long long)(un * 2 + kb) * 2 + i) * 64];                          \
     }
-// the 16 k of a unit in the order 0,4,1,5,2,6,3,7 | 8,12,9,13,...: component j of k-block kb holds k = 8*kb + j (+4 in the upper lanes)
-// One unit (16 k = 48 MFMAs).  Everything else a wave has to issue rides in the shadow of the MFMAs, one item per k-pair,
-// because the wave issues in order and anything in front of a dependent MFMA idles the matrix pipe:
-//   * the six loads of the unit three ahead (XL / WQL / W8L <- UNITL);
-//   * the eight lane swaps that turn the NEXT unit's packed k-blocks (XS) into "row = lane" operands (BN): a swap right before
-//     the MFMA that consumes it costs ~21 cycles of pipe idle (measured), a whole unit earlier it costs nothing.
-#define WMAR_FX_SWAP(BDST, XS, SLOT)                                                             \
-    {                                                                                             \
-        const int kb_ = (SLOT) >> 2, j_ = (SLOT) & 3;                                             \
-        const float c0 = j_ == 0 ? XS[kb_][0].x : (j_ == 1 ? XS[kb_][0].y : (j_ == 2 ? XS[kb_][0].z : XS[kb_][0].w)); \
-        const float c1 = j_ == 0 ? XS[kb_][1].x : (j_ == 1 ? XS[kb_][1].y : (j_ == 2 ? XS[kb_][1].z : XS[kb_][1].w)); \
-        if (FX_ABL & 2) { BDST[SLOT][0] = c0; BDST[SLOT][1] = c1; }                               \
-        else {                                                                                    \
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(c0), __float_as_uint(c1), false, false); \
-            BDST[SLOT][0] = __uint_as_float(sw[0]); BDST[SLOT][1] = __uint_as_float(sw[1]);       \
-        }                                                                                         \
-    }
-#define WMAR_FX_MMA(BC, WQ, W8V, BN, XS, XL, WQL, W8L, UNITL)                                    \
-    {                                                                                             \
-        const int un_ = (UNITL);                                                                  \
-        _Pragma("unroll") for (int slot = 0; slot < 8; ++slot) {                                  \
-            const int kb = slot >> 2, j = slot & 3;                                               \
-            /* k16 = 8*kb + j (register q = 2*kb, block j) and k16 + 4 (register q = 2*kb + 1, block j) */ \
-            const float aq0 = kb == 0 ? WQ.x : WQ.z, aq1 = kb == 0 ? WQ.y : WQ.w;                 \
-            /* every non-MFMA instruction directly behind a 16x16 MFMA: it issues inside that instruction's 32 cycles */ \
-            fx16(acc16, BC[slot][0], aq0, j);                                                     \
-            WMAR_FX_SWAP(BN, XS, slot)                                                            \
-            __builtin_amdgcn_sched_barrier(0);                                                    \
-            fx4(acc4a, acc4b, BC[slot][0], W8V, 8 * kb + j);                                      \
-            __builtin_amdgcn_sched_barrier(0);                                                    \
-            fx16(acc16, BC[slot][1], aq1, j);                                                     \
-            if (!(FX_ABL & 1)) {                                                                  \
-                if (slot == 0) WQL = ld_nt(W16 + (long long)un_ * 64);                            \
-                if (slot == 1) W8L = ld_nt2(W8 + (long long)un_ * 64);                            \
-                if (slot >= 2 && slot < 6)                                                        \
-                    XL[(slot - 2) >> 1][(slot - 2) & 1] = Xp[((long long)(un_ * 2 + ((slot - 2) >> 1)) * 2 + ((slot - 2) & 1)) * 64]; \
-            }                                                                                     \
-            __builtin_amdgcn_sched_barrier(0);                                                    \
-            fx4(acc4a, acc4b, BC[slot][1], W8V, 8 * kb + 4 + j);                                  \
-            __builtin_amdgcn_sched_barrier(0);                                                    \
-        }                                                                                         \
-    }
-    // (the block / k16 immediates need compile-time constants: dispatch through a switch on unrolled indices)
-    auto fx16 = [&](f32x16& c16, float bv, float aq, int j) {          // the 32-cycle instruction: block j of the A register
-        if (j == 0) c16 = __builtin_amdgcn_mfma_f32_16x16x1f32(aq, bv, c16, 2, 0, 0);
-        if (j == 1) c16 = __builtin_amdgcn_mfma_f32_16x16x1f32(aq, bv, c16, 2, 1, 0);
-        if (j == 2) c16 = __builtin_amdgcn_mfma_f32_16x16x1f32(aq, bv, c16, 2, 2, 0);
-        if (j == 3) c16 = __builtin_amdgcn_mfma_f32_16x16x1f32(aq, bv, c16, 2, 3, 0);
+    // (the block-select immediates need compile-time constants: chains of ifs over the unrolled indices fold away)
+    auto fx16 = [&](f32x16& c16, float bv, float aq, int sel) {          // 32 cycles; sel = pair & 1
+        if (sel == 0) c16 = __builtin_amdgcn_mfma_f32_16x16x1f32(aq, bv, c16, 1, 0, 0);
+        if (sel == 1) c16 = __builtin_amdgcn_mfma_f32_16x16x1f32(aq, bv, c16, 1, 1, 0);
     };
-    auto fx4 = [&](f32x4& c4a, f32x4& c4b, float bv, const float2& w8v, int k16) {     // the two 8-cycle instructions: block k16
+    auto fx4 = [&](f32x4& c4a, f32x4& c4b, float bv, const float2& w8v, int pair) {     // 2 x 8 cycles
         if (FX_ABL & 4) return;
-#define WMAR_FX_CASE(KV)                                                                          \
-        if (k16 == KV) {                                                                          \
-            c4a = __builtin_amdgcn_mfma_f32_4x4x1f32(w8v.x, bv, c4a, 4, KV, 0);                   \
-            c4b = __builtin_amdgcn_mfma_f32_4x4x1f32(w8v.y, bv, c4b, 4, KV, 0);                   \
+#define WMAR_FX_CASE(PV)                                                                          \
+        if (pair == PV) {                                                                         \
+            c4a = __builtin_amdgcn_mfma_f32_4x4x1f32(w8v.x, bv, c4a, 3, PV, 0);                   \
+            c4b = __builtin_amdgcn_mfma_f32_4x4x1f32(w8v.y, bv, c4b, 3, PV, 0);                   \
         }
         WMAR_FX_CASE(0) WMAR_FX_CASE(1) WMAR_FX_CASE(2) WMAR_FX_CASE(3) WMAR_FX_CASE(4) WMAR_FX_CASE(5) WMAR_FX_CASE(6) WMAR_FX_CASE(7)
-        WMAR_FX_CASE(8) WMAR_FX_CASE(9) WMAR_FX_CASE(10) WMAR_FX_CASE(11) WMAR_FX_CASE(12) WMAR_FX_CASE(13) WMAR_FX_CASE(14) WMAR_FX_CASE(15)
 #undef WMAR_FX_CASE
     };
+// One unit (16 k = 8 pairs x 6 MFMAs); the six loads of the unit three ahead ride one per pair behind a 16x16 MFMA: a wave issues
+// in order, so anything in front of an MFMA that is ready idles the matrix pipe.
+#define WMAR_FX_MMA(XC, WQ, W8V, XL, WQL, W8L, UNITL)                                            \
+    {                                                                                             \
+        const int un_ = (UNITL);                                                                  \
+        _Pragma("unroll") for (int pair = 0; pair < 8; ++pair) {                                  \
+            const int kb = pair >> 2, j = pair & 3, q = pair >> 1;                                \
+            const float aq = q == 0 ? WQ.x : (q == 1 ? WQ.y : (q == 2 ? WQ.z : WQ.w));            \
+            const float b0 = j == 0 ? XC[kb][0].x : (j == 1 ? XC[kb][0].y : (j == 2 ? XC[kb][0].z : XC[kb][0].w)); \
+            const float b1 = j == 0 ? XC[kb][1].x : (j == 1 ? XC[kb][1].y : (j == 2 ? XC[kb][1].z : XC[kb][1].w)); \
+            fx16(acc16[0], b0, aq, pair & 1);                                                     \
+            if (!(FX_ABL & 1)) {                                                                  \
+                if (pair == 0) WQL = ld_nt(W16 + (long long)un_ * 64);                            \
+                if (pair == 1) W8L = ld_nt2(W8 + (long long)un_ * 64);                            \
+                if (pair >= 2 && pair < 6)                                                        \
+                    XL[(pair - 2) >> 1][(pair - 2) & 1] = Xp[((long long)(un_ * 2 + ((pair - 2) >> 1)) * 2 + ((pair - 2) & 1)) * 64]; \
+            }                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);   /* hipcc otherwise clusters the dependent MFMAs of one accumulator */ \
+            fx4(acc4a[0], acc4b[0], b0, W8V, pair);                                               \
+            fx16(acc16[1], b1, aq, pair & 1);                                                     \
+            fx4(acc4a[1], acc4b[1], b1, W8V, pair);                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+        }                                                                                         \
+    }
 
 #ifdef WMAR_FX_TRACE
     const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
@@ -646,30 +634,42 @@ static __global__ __launch_bounds__(256) void k_fc1x(Fc1xArgs a) {
     const unsigned long long tr1 = __builtin_amdgcn_s_memtime();
 #endif
 #define WMAR_FX_NEXT(I) WMAR_FX_UNIT((I) < per ? (I) : (I) - per)     /* past the end: an in-bounds re-read instead of a branch */
-    float bA[8][2], bB[8][2];
-#pragma unroll
-    for (int slot = 0; slot < 8; ++slot) WMAR_FX_SWAP(bA, xA, slot)
     for (int it = 0; it < per; it += 4) {
-        WMAR_FX_MMA(bA, wqA, w8A, bB, xB, xD, wqD, w8D, WMAR_FX_NEXT(it + 3))
-        WMAR_FX_MMA(bB, wqB, w8B, bA, xC, xA, wqA, w8A, WMAR_FX_NEXT(it + 4))
-        WMAR_FX_MMA(bA, wqC, w8C, bB, xD, xB, wqB, w8B, WMAR_FX_NEXT(it + 5))
-        WMAR_FX_MMA(bB, wqD, w8D, bA, xA, xC, wqC, w8C, WMAR_FX_NEXT(it + 6))
+        WMAR_FX_MMA(xA, wqA, w8A, xD, wqD, w8D, WMAR_FX_NEXT(it + 3))
+        WMAR_FX_MMA(xB, wqB, w8B, xA, wqA, w8A, WMAR_FX_NEXT(it + 4))
+        WMAR_FX_MMA(xC, wqC, w8C, xB, wqB, w8B, WMAR_FX_NEXT(it + 5))
+        WMAR_FX_MMA(xD, wqD, w8D, xC, wqC, w8C, WMAR_FX_NEXT(it + 6))
     }
 #undef WMAR_FX_NEXT
 #undef WMAR_FX_LOAD
 #undef WMAR_FX_MMA
-#undef WMAR_FX_SWAP
 #undef WMAR_FX_UNIT
 
 #ifdef WMAR_FX_TRACE
     const unsigned long long tr2 = __builtin_amdgcn_s_memtime();
 #endif
-    // cross-wave K reduction in LDS (fixed order), LayerNorm algebra, bias, GELU, packed store
+    // "k" + "k+4" partial sums, then the cross-wave K reduction in LDS (fixed order), LayerNorm algebra, bias, GELU, packed store.
+    // red[w][g]: g = 2*i + b: 16x16 part, rows 32 i + 16 b + lane%16, columns 4*(lane/16)..+3;  g = 4 / 5: columns 16-19 / 20-23, row = lane
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
-        red[w][b][lane] = make_float4(acc16[4 * b + 0], acc16[4 * b + 1], acc16[4 * b + 2], acc16[4 * b + 3]);
-    red[w][4][lane] = make_float4(acc4a[0], acc4a[1], acc4a[2], acc4a[3]);
-    red[w][5][lane] = make_float4(acc4b[0], acc4b[1], acc4b[2], acc4b[3]);
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            red[w][2 * i + b][lane] = make_float4(acc16[i][4 * b + 0] + acc16[i][4 * b + 8], acc16[i][4 * b + 1] + acc16[i][4 * b + 9],
+                                                  acc16[i][4 * b + 2] + acc16[i][4 * b + 10], acc16[i][4 * b + 3] + acc16[i][4 * b + 11]);
+    {
+        float v4[2][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            // lanes l and l+32 of a 4x4 accumulator hold the two partial sums of row 32 i + l: the swap lines them up as
+            // [tile 0 | tile 1] rows in lane order
+            const auto sa = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc4a[0][r]), __float_as_uint(acc4a[1][r]), false, false);
+            const auto sb = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc4b[0][r]), __float_as_uint(acc4b[1][r]), false, false);
+            v4[0][r] = __uint_as_float(sa[0]) + __uint_as_float(sa[1]);
+            v4[1][r] = __uint_as_float(sb[0]) + __uint_as_float(sb[1]);
+        }
+        red[w][4][lane] = make_float4(v4[0][0], v4[0][1], v4[0][2], v4[0][3]);
+        red[w][5][lane] = make_float4(v4[1][0], v4[1][1], v4[1][2], v4[1][3]);
+    }
     __syncthreads();
     for (int gi = w; gi < 6; gi += 4) {
         float o[4] = {0.f, 0.f, 0.f, 0.f};
@@ -678,7 +678,6 @@ static __global__ __launch_bounds__(256) void k_fc1x(Fc1xArgs a) {
             const float4 t = red[ww][gi][lane];
             o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
         }
-        // accumulator layouts: 16x16 block b = gi: columns 4*(lane/16) .. +3 of row 16*b + lane%16;  4x4: columns 16 + 4*(gi-4) .. +3 of row lane
         const int m = gi < 4 ? 16 * gi + (lane & 15) : lane;
         const int n = tile * 24 + (gi < 4 ? 4 * (lane >> 4) : 16 + 4 * (gi - 4));
         const float mm = __shfl(mu, m), rs = __shfl(rstd, m);
