@@ -1,7 +1,8 @@
 """Dev tool: time the full-size Taming GPT decode loop (random weights)."""
-import sys, time
+import os, sys, time
 import torch
-sys.path.insert(0, ".")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from wmar_amd.utils import synth
 from wmar_amd.models.engine import GPTEngine
 from wmar_amd.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
@@ -16,7 +17,7 @@ torch.cuda.synchronize(); print("weights", time.time() - t0)
 eng = GPTEngine(cfg, sd, max_batch=max(B, 1)); del sd; torch.cuda.empty_cache()
 print("engine bytes", eng.device_bytes / 1e9)
 ids = []
-for line in open("wmar_amd/assets/vqgan_alive_ids.txt"): ids.extend(int(t) for t in line.split(","))
+for line in open(os.path.join(ROOT, "wmar_amd/assets/vqgan_alive_ids.txt")): ids.extend(int(t) for t in line.split(","))
 dead = sorted(set(range(16384)) - set(ids))
 wm = GentimeWatermark({"alive_ids": torch.tensor(ids), "dead_ids": torch.tensor(dead), "embedding": None}, 16384,
                       SeedStrategy.LINEAR, SplitStrategy.RANDOM_STRATIFIED, 1, 2.0, 0.25, device="cuda")
