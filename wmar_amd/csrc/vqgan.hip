@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "common.h"
+#include "bx_split.h"
 
 namespace wmar {
 
@@ -51,6 +52,26 @@ __global__ void k_pack_conv(const float* __restrict__ W, float4* __restrict__ Wp
     Wp[idx] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// W [Cout][Cin][ks][ks] -> Wq[ct][tap][cin/16][piece][lane] (16 bytes = 8 bf16): lane holds cout = 32 ct + lane % 32, input channels
+// 16 k16 + 8 (lane / 32) + 0..7 -- the A operand of v_mfma_f32_32x32x16_bf16, one plane per bf16 piece of the weight (bx_split.h).
+__global__ void k_pack_conv_bx(const float* __restrict__ W, u32x4* __restrict__ Wq, int Cout, int Cin, int ks, int CT, int KU) {
+    const int T = ks * ks;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)CT * T * KU * 64) return;
+    const int lane = (int)(idx & 63);
+    long long r = idx >> 6;
+    const int ku = (int)(r % KU); r /= KU;
+    const int tap = (int)(r % T);
+    const int ct = (int)(r / T);
+    const int co = ct * 32 + (lane & 31), ci0 = ku * 16 + 8 * (lane >> 5);
+    float v[8];
+    for (int i = 0; i < 8; ++i) v[i] = (co < Cout && ci0 + i < Cin) ? W[((long long)co * Cin + ci0 + i) * T + tap] : 0.f;
+    unsigned h[4], m[4], l[4];
+    for (int i = 0; i < 4; ++i) bx_split2(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
+    u32x4* o = Wq + (idx >> 6) * 192 + lane;
+    o[0] = u32x4{h[0], h[1], h[2], h[3]}; o[64] = u32x4{m[0], m[1], m[2], m[3]}; o[128] = u32x4{l[0], l[1], l[2], l[3]};
+}
+
 __global__ void k_pad_vec(const float* __restrict__ src, float* __restrict__ dst, int n, int npad) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < npad) dst[i] = i < n ? src[i] : 0.f;
@@ -60,6 +81,7 @@ __global__ void k_pad_vec(const float* __restrict__ src, float* __restrict__ dst
 struct ConvArgs {
     const float* in;     // NHWC [B][Hs][Ws][Cin]  (Hs,Ws = stored size; the conv sees 2x that when up=1)
     const float4* wp;
+    const u32x4* wq;     // k_conv_bx: the weights as bf16 pieces (k_pack_conv_bx)
     const float* bias;   // [CT*32]
     const float* res;    // nullable NHWC [B][Ho][Wo][Cout_s]
     float* out;          // NHWC [B][Ho][Wo][Cout_s]
@@ -97,6 +119,60 @@ __device__ __forceinline__ float4 conv_gn(const ConvArgs& a, float4 v, int b, in
 #pragma unroll
         for (int i = 0; i < 4; ++i) r[i] = r[i] / (1.0f + __expf(-r[i]));
     return make_float4(r[0], r[1], r[2], r[3]);
+}
+
+// Epilogue of both conv kernels: bias (+ residual), NHWC store, per-tile GroupNorm partial sums of the output.
+__device__ __forceinline__ void conv_store(const ConvArgs& a, const f32x16 (&acc)[2], int b, int ct, int ty, int tx, int lane) {
+    const int j = lane & 31, half = lane >> 5;
+    const int prow = j >> 3, pcol = j & 7;
+    const int oy0 = ty * 8, ox0 = tx * 8;
+    // epilogue: lane holds pixel j of each half-tile and couts ct*32 + 8g + 4*half + {0..3}
+    double gs[4] = {0.0, 0.0, 0.0, 0.0}, gss[4] = {0.0, 0.0, 0.0, 0.0};   // this lane's sums per g over its 2 pixels x 4 channels
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int oy = oy0 + p * 4 + prow, ox = ox0 + pcol;
+        const long long pix = ((long long)b * a.Ho + oy) * a.Wo + ox;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = ct * 32 + g * 8 + half * 4;
+            if (co >= a.Cout_s) continue;
+            const float4 bb = *(const float4*)(a.bias + co);
+            float4 o = make_float4(acc[p][g * 4 + 0] + bb.x, acc[p][g * 4 + 1] + bb.y, acc[p][g * 4 + 2] + bb.z,
+                                   acc[p][g * 4 + 3] + bb.w);
+            if (a.res) {
+                const float4 rr = *(const float4*)(a.res + pix * a.Cout_s + co);
+                o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+            }
+            *(float4*)(a.out + pix * a.Cout_s + co) = o;
+            if (a.st_part) {
+                gs[g] += (double)o.x + (double)o.y + (double)o.z + (double)o.w;
+                gss[g] += (double)o.x * o.x + (double)o.y * o.y + (double)o.z * o.z + (double)o.w * o.w;
+            }
+        }
+    }
+    if (a.st_part) {
+        // fold the 32 pixels of a lane half (always), the two halves (groups of >= 8 channels) and pairs of g (16 channels)
+        const int top = a.st_cpg >= 8 ? 32 : 16;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            for (int o = 1; o <= top; o <<= 1) { gs[g] += __shfl_xor(gs[g], o); gss[g] += __shfl_xor(gss[g], o); }
+        if (a.st_cpg == 16) { gs[0] += gs[1]; gss[0] += gss[1]; gs[2] += gs[3]; gss[2] += gss[3]; }
+        const long long tile = ((long long)b * a.tiles_y + ty) * a.tiles_x + tx;
+        double* dst = a.st_part + tile * 64;
+        if (a.st_cpg == 4) {              // group = ct*8 + 2g + half: lanes 0 and 32 each write four groups
+            if ((lane & 31) == 0)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { const int grp = ct * 8 + 2 * g + half; dst[grp * 2] = gs[g]; dst[grp * 2 + 1] = gss[g]; }
+        } else if (lane == 0) {
+            if (a.st_cpg == 8) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { const int grp = ct * 4 + g; dst[grp * 2] = gs[g]; dst[grp * 2 + 1] = gss[g]; }
+            } else {
+                dst[(ct * 2) * 2] = gs[0]; dst[(ct * 2) * 2 + 1] = gss[0];
+                dst[(ct * 2 + 1) * 2] = gs[2]; dst[(ct * 2 + 1) * 2 + 1] = gss[2];
+            }
+        }
+    }
 }
 
 constexpr int CONV_CCH = 32;          // input channels staged per LDS round
@@ -237,53 +313,143 @@ __global__ __launch_bounds__(COT * 64) void k_conv(ConvArgs a) {
     }
 #undef WMAR_CONV_ROUND
     if (!active) return;
-    // epilogue: lane holds pixel j of each half-tile and couts ct*32 + 8g + 4*half + {0..3}
-    double gs[4] = {0.0, 0.0, 0.0, 0.0}, gss[4] = {0.0, 0.0, 0.0, 0.0};   // this lane's sums per g over its 2 pixels x 4 channels
+    conv_store(a, acc, b, ct, ty, tx, lane);
+}
+
+// ---- the same conv on the bf16 matrix pipe (bx_split.h): full 32-channel rounds, double-buffered staging.
+// The patch is staged as the three bf16 pieces of every (normalised, swished) input value -- [pixel][piece][32 channels], 208 bytes
+// per pixel (192 + 16 of padding: eight consecutive pixels' 16-byte reads cover all 32 LDS banks) -- and a wave reads one
+// 16-byte B operand per (pixel tile, piece, 16 channels).  The weights arrive pre-split (k_pack_conv_bx).  Per (tap, 16 channels):
+// 3 + 6 operand loads and 12 MFMAs of 32 cycles, against 16 MFMAs of 64 cycles in k_conv.
+constexpr int CONV_PSTRIDE_BX = 208;   // bytes per staged pixel
+
+template <int COT, int KS>
+__global__ __launch_bounds__(COT * 64) void k_conv_bx(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char patchb[];  // [2][PH*PW][CONV_PSTRIDE_BX]
+    constexpr int T = KS * KS, NIT = 2 * T;      // (tap, 16-channel half) steps per 32-channel round
+    constexpr int PW = 7 + KS, PH = PW;          // stride 1 only (host)
+    // register rings: weights WR - 1 steps ahead (L2), patch operands one (LDS); a step's slot is its index in the round modulo the
+    // ring, so the ring length must divide the steps of a round for the prefetch across the round boundary to land in the right slot
+    constexpr int WR = NIT % 3 == 0 ? 3 : 2, XR = 2;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int bid = blockIdx.x;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+    const int cgroups = (a.CT + COT - 1) / COT;
+    const int cg = bid % cgroups;
+    const int b = bid / cgroups;
+    const int ct = cg * COT + w;
+    const bool active = ct < a.CT;
+    const int iy0 = ty * 8 - a.pad, ix0 = tx * 8 - a.pad;
+    const int Hc = a.up ? a.Hs * 2 : a.Hs, Wc = a.up ? a.Ws * 2 : a.Ws;  // size the conv sees
+    const int KU = a.Cin >> 4;
+
+    f32x16 acc[2];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int oy = oy0 + p * 4 + prow, ox = ox0 + pcol;
-        const long long pix = ((long long)b * a.Ho + oy) * a.Wo + ox;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int co = ct * 32 + g * 8 + half * 4;
-            if (co >= a.Cout_s) continue;
-            const float4 bb = *(const float4*)(a.bias + co);
-            float4 o = make_float4(acc[p][g * 4 + 0] + bb.x, acc[p][g * 4 + 1] + bb.y, acc[p][g * 4 + 2] + bb.z,
-                                   acc[p][g * 4 + 3] + bb.w);
-            if (a.res) {
-                const float4 rr = *(const float4*)(a.res + pix * a.Cout_s + co);
-                o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
-            }
-            *(float4*)(a.out + pix * a.Cout_s + co) = o;
-            if (a.st_part) {
-                gs[g] += (double)o.x + (double)o.y + (double)o.z + (double)o.w;
-                gss[g] += (double)o.x * o.x + (double)o.y * o.y + (double)o.z * o.z + (double)o.w * o.w;
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int j = lane & 31, half = lane >> 5;
+    const int prow = j >> 3, pcol = j & 7;
+    const float* inb = a.in + (long long)b * a.Hs * a.Ws * a.Cin;
+
+    constexpr int NPT = 4;
+    constexpr int nelem = PH * PW * 8;
+    long long goff[NPT];
+    int loff[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int e = threadIdx.x + i * COT * 64;
+        goff[i] = -1; loff[i] = -1;
+        if (e < nelem) {
+            const int pix = e >> 3, qq = e & 7;
+            const int py = pix / PW, px = pix - py * PW;
+            int y = iy0 + py, x = ix0 + px;
+            loff[i] = pix * CONV_PSTRIDE_BX + qq * 8;
+            if (y >= 0 && y < Hc && x >= 0 && x < Wc) {
+                if (a.up) { y >>= 1; x >>= 1; }
+                goff[i] = ((long long)y * a.Ws + x) * a.Cin + qq * 4;
             }
         }
     }
-    if (a.st_part) {
-        // fold the 32 pixels of a lane half (always), the two halves (groups of >= 8 channels) and pairs of g (16 channels)
-        const int top = a.st_cpg >= 8 ? 32 : 16;
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            for (int o = 1; o <= top; o <<= 1) { gs[g] += __shfl_xor(gs[g], o); gss[g] += __shfl_xor(gss[g], o); }
-        if (a.st_cpg == 16) { gs[0] += gs[1]; gss[0] += gss[1]; gs[2] += gs[3]; gss[2] += gss[3]; }
-        const long long tile = ((long long)b * a.tiles_y + ty) * a.tiles_x + tx;
-        double* dst = a.st_part + tile * 64;
-        if (a.st_cpg == 4) {              // group = ct*8 + 2g + half: lanes 0 and 32 each write four groups
-            if ((lane & 31) == 0)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) { const int grp = ct * 8 + 2 * g + half; dst[grp * 2] = gs[g]; dst[grp * 2 + 1] = gss[g]; }
-        } else if (lane == 0) {
-            if (a.st_cpg == 8) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) { const int grp = ct * 4 + g; dst[grp * 2] = gs[g]; dst[grp * 2 + 1] = gss[g]; }
-            } else {
-                dst[(ct * 2) * 2] = gs[0]; dst[(ct * 2) * 2 + 1] = gss[0];
-                dst[(ct * 2 + 1) * 2] = gs[2]; dst[(ct * 2 + 1) * 2 + 1] = gss[2];
-            }
+    constexpr int psz = PH * PW * CONV_PSTRIDE_BX;
+    float4 pr[NPT];
+    // normalise (+ swish), split, store the three pieces of this thread's four channels (8 bytes each)
+#define WMAR_CONVBX_STAGE(DST, C0)                                                                              \
+    _Pragma("unroll") for (int i = 0; i < NPT; ++i)                                                             \
+        if (loff[i] >= 0) {                                                                                     \
+            if (a.gn_mr && goff[i] >= 0) pr[i] = conv_gn(a, pr[i], b, (C0) + (threadIdx.x + i * COT * 64) % 8 * 4); \
+            unsigned h0, m0, l0, h1, m1, l1;                                                                    \
+            bx_split2(pr[i].x, pr[i].y, h0, m0, l0);                                                            \
+            bx_split2(pr[i].z, pr[i].w, h1, m1, l1);                                                            \
+            unsigned char* d = (DST) + loff[i];                                                                 \
+            *(u32x2*)d = u32x2{h0, h1}; *(u32x2*)(d + 64) = u32x2{m0, m1}; *(u32x2*)(d + 128) = u32x2{l0, l1};  \
         }
+#define WMAR_CONVBX_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
+    // step it of round r: tap = it / 2, channels 32 r + 16 (it % 2) .. + 15
+    const u32x4* wtile = a.wq + (long long)(active ? ct : 0) * T * KU * 192 + lane;
+    u32x4 wr[WR][3], xr[XR][6];
+#define WMAR_CONVBX_LOADW(SLOT, R, IT)                                                                          \
+    { const u32x4* wp_ = wtile + ((long long)((IT) >> 1) * KU + 2 * (R) + ((IT) & 1)) * 192;                       \
+      wr[SLOT][0] = wp_[0]; wr[SLOT][1] = wp_[64]; wr[SLOT][2] = wp_[128]; }
+    const int lbase = (prow * PW + pcol) * CONV_PSTRIDE_BX + half * 16;
+#define WMAR_CONVBX_LOADX(SLOT, CUR, IT)                                                                        \
+    { const int dy_ = ((IT) >> 1) / KS, dx_ = ((IT) >> 1) % KS;                                                  \
+      const unsigned char* p0_ = (CUR) + lbase + (dy_ * PW + dx_) * CONV_PSTRIDE_BX + ((IT) & 1) * 32;            \
+      const unsigned char* p1_ = p0_ + 4 * PW * CONV_PSTRIDE_BX;                                                 \
+      xr[SLOT][0] = *(const u32x4*)p0_; xr[SLOT][1] = *(const u32x4*)(p0_ + 64); xr[SLOT][2] = *(const u32x4*)(p0_ + 128); \
+      xr[SLOT][3] = *(const u32x4*)p1_; xr[SLOT][4] = *(const u32x4*)(p1_ + 64); xr[SLOT][5] = *(const u32x4*)(p1_ + 128); }
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) pr[i] = goff[i] >= 0 ? *(const float4*)(inb + goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    WMAR_CONVBX_LOADW(0, 0, 0)
+    if (WR > 2) { WMAR_CONVBX_LOADW(1, 0, 1) }
+    WMAR_CONVBX_STAGE(patchb, 0)
+    __syncthreads();
+    int buf = 0;
+    const int rounds = a.Cin / CONV_CCH;
+    for (int r = 0; r < rounds; ++r) {
+        const bool more = r + 1 < rounds;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < NPT; ++i)
+                pr[i] = goff[i] >= 0 ? *(const float4*)(inb + goff[i] + (r + 1) * CONV_CCH) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const unsigned char* cur = patchb + buf * psz;
+        WMAR_CONVBX_LOADX(0, cur, 0)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            // weights of step it + WR - 1 (the next round's first steps at the end of this one), patch operands of step it + 1
+            if (it + WR - 1 < NIT) { WMAR_CONVBX_LOADW((it + WR - 1) % WR, r, it + WR - 1) }
+            else if (more) { WMAR_CONVBX_LOADW((it + WR - 1) % WR, r + 1, it + WR - 1 - NIT) }
+            if (it + 1 < NIT) { WMAR_CONVBX_LOADX((it + 1) % XR, cur, it + 1) }
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4 wh = wr[it % WR][0], wm = wr[it % WR][1], wl = wr[it % WR][2];
+            const u32x4 x0h = xr[it % XR][0], x0m = xr[it % XR][1], x0l = xr[it % XR][2];
+            const u32x4 x1h = xr[it % XR][3], x1m = xr[it % XR][4], x1l = xr[it % XR][5];
+            // the small products first
+            WMAR_CONVBX_MFMA(wl, x0h, acc[0]); WMAR_CONVBX_MFMA(wl, x1h, acc[1]);
+            WMAR_CONVBX_MFMA(wh, x0l, acc[0]); WMAR_CONVBX_MFMA(wh, x1l, acc[1]);
+            WMAR_CONVBX_MFMA(wm, x0m, acc[0]); WMAR_CONVBX_MFMA(wm, x1m, acc[1]);
+            WMAR_CONVBX_MFMA(wm, x0h, acc[0]); WMAR_CONVBX_MFMA(wm, x1h, acc[1]);
+            WMAR_CONVBX_MFMA(wh, x0m, acc[0]); WMAR_CONVBX_MFMA(wh, x1m, acc[1]);
+            WMAR_CONVBX_MFMA(wh, x0h, acc[0]); WMAR_CONVBX_MFMA(wh, x1h, acc[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) {
+            unsigned char* nxt = patchb + (buf ^ 1) * psz;
+            WMAR_CONVBX_STAGE(nxt, (r + 1) * CONV_CCH)
+        }
+        __syncthreads();
+        buf ^= 1;
     }
+#undef WMAR_CONVBX_STAGE
+#undef WMAR_CONVBX_MFMA
+#undef WMAR_CONVBX_LOADW
+#undef WMAR_CONVBX_LOADX
+    if (!active) return;
+    conv_store(a, acc, b, ct, ty, tx, lane);
 }
 
 // ------------------------------------------------------------------------ GroupNorm
@@ -570,6 +736,7 @@ using namespace wmar;
 // ------------------------------------------------------------------------------ engine
 struct ConvW {
     float4* wp = nullptr;
+    u32x4* wq = nullptr;     // bf16 pieces for k_conv_bx (input channels a multiple of 32)
     float* bias = nullptr;
     int cin = 0, cout = 0, cin_s = 0, cout_s = 0, ks = 1, CT = 0, KBc = 0;
 };
@@ -673,6 +840,12 @@ struct Loader {
         if (bsrc) hipLaunchKernelGGL(k_pad_vec, dim3((c.CT * 32 + 255) / 256), dim3(256), 0, st, bsrc, c.bias, cout, c.CT * 32);
         else if (hipMemsetAsync(c.bias, 0, (size_t)c.CT * 32 * 4, st) != hipSuccess) { set_error("bias memset failed"); rc = WMAR_EHIP; return; }
         rc = launch_status("k_pack_conv");
+        if (rc == WMAR_OK && c.cin_s % CONV_CCH == 0) {
+            const size_t nq = (size_t)c.CT * ks * ks * (c.cin_s / 16) * 64;
+            if ((rc = v->alloc(&c.wq, nq * 3))) return;
+            hipLaunchKernelGGL(k_pack_conv_bx, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, W, c.wq, cout, cin, ks, c.CT, c.cin_s / 16);
+            rc = launch_status("k_pack_conv_bx");
+        }
     }
     void norm(const std::string& p, int C, NormW& n) {
         const float* g = need(p + ".weight");
@@ -710,6 +883,11 @@ bool in_attn_res(const wmar_vq_config& c, int res) {
 }
 
 #ifdef WMAR_DEV_KNOBS
+static bool conv_no_bx() { static int v = -1; if (v < 0) v = getenv("WMAR_CONV_NO_BX") ? 1 : 0; return v != 0; }
+#else
+static constexpr bool conv_no_bx() { return false; }
+#endif
+#ifdef WMAR_DEV_KNOBS
 static bool vq_trace() { static int v = -1; if (v < 0) { const char* e = getenv("WMAR_VQ_TRACE"); v = e ? atoi(e) : 0; } return v != 0; }
 #else
 static constexpr bool vq_trace() { return false; }
@@ -735,7 +913,7 @@ int run_conv(const ConvW& c, const float* in, float* out, const float* res, int 
         WMAR_REQUIRE(gn->C == c.cin_s && !up, "fused GroupNorm: channel count %d != conv input %d", gn->C, c.cin_s);
         a.gn_mr = gn->mr; a.gn_g = gn->g; a.gn_b = gn->b; a.gn_cpg = gn->C / 32; a.gn_swish = gn->swish;
     }
-    a.in = in; a.wp = c.wp; a.bias = c.bias; a.res = res; a.out = out;
+    a.in = in; a.wp = c.wp; a.wq = c.wq; a.bias = c.bias; a.res = res; a.out = out;
     a.Hs = Hs; a.Ws = Ws; a.Cin = c.cin_s;
     const int Hc = up ? 2 * Hs : Hs, Wc = up ? 2 * Ws : Ws;
     a.Ho = stride == 2 ? Hc / 2 : Hc; a.Wo = stride == 2 ? Wc / 2 : Wc;
@@ -752,12 +930,19 @@ int run_conv(const ConvW& c, const float* in, float* out, const float* res, int 
                        (long long)B * a.tiles_x * a.tiles_y * 64 <= g_trk.cap;
     if (stats) { a.st_part = g_trk.part; a.st_cpg = cpg_out; g_trk.src = out; g_trk.tiles = a.tiles_x * a.tiles_y; g_trk.C = c.cout; }
     else if (g_trk.src == out) g_trk.src = nullptr;      // the tensor the buffer described is being overwritten
-    const size_t lds = (size_t)(a.dbuf ? 2 : 1) * PW * PW * CONV_PSTRIDE * sizeof(float);
+    const bool bx = a.dbuf && c.wq && stride == 1 && (c.ks == 3 || c.ks == 1) && !conv_no_bx();
+    const size_t lds = bx ? (size_t)2 * PW * PW * CONV_PSTRIDE_BX : (size_t)(a.dbuf ? 2 : 1) * PW * PW * CONV_PSTRIDE * sizeof(float);
     const int cgroups = (c.CT + COT - 1) / COT;
     const unsigned grid = (unsigned)((long long)B * cgroups * a.tiles_x * a.tiles_y);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (vq_trace()) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
-    if (COT == 4) hipLaunchKernelGGL(k_conv<4>, dim3(grid), dim3(256), lds, st, a);
+    if (bx && COT == 4 && c.ks == 3) hipLaunchKernelGGL((k_conv_bx<4, 3>), dim3(grid), dim3(256), lds, st, a);
+    else if (bx && COT == 4) hipLaunchKernelGGL((k_conv_bx<4, 1>), dim3(grid), dim3(256), lds, st, a);
+    else if (bx && COT == 2 && c.ks == 3) hipLaunchKernelGGL((k_conv_bx<2, 3>), dim3(grid), dim3(128), lds, st, a);
+    else if (bx && COT == 2) hipLaunchKernelGGL((k_conv_bx<2, 1>), dim3(grid), dim3(128), lds, st, a);
+    else if (bx && c.ks == 3) hipLaunchKernelGGL((k_conv_bx<1, 3>), dim3(grid), dim3(64), lds, st, a);
+    else if (bx) hipLaunchKernelGGL((k_conv_bx<1, 1>), dim3(grid), dim3(64), lds, st, a);
+    else if (COT == 4) hipLaunchKernelGGL(k_conv<4>, dim3(grid), dim3(256), lds, st, a);
     else if (COT == 2) hipLaunchKernelGGL(k_conv<2>, dim3(grid), dim3(128), lds, st, a);
     else hipLaunchKernelGGL(k_conv<1>, dim3(grid), dim3(64), lds, st, a);
     if (vq_trace()) {
