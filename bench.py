@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 B = 64
 GEN = dict(batch_size=B, temperature=1.0, top_k=250, top_p=0.92)
 PEAK_F32_MFMA_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TF = 2500.0     # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E spec
 METRIC = "watermarked images/sec at 256x256 (16x16 tok), batch 64; detector p-value delta vs ref"
 
@@ -253,8 +254,14 @@ def gpu_analysis(model, wm, extra, cond, args, world, log):
     out = {"roofline": roofline, "roofline_by_role": roles,
            "decode_step": {"ms": round(step_ms, 3), "roofline_ms": round(step_roofline_ms, 3), "frac": round(step_roofline_ms / step_ms, 3),
                            "gemm_TFLOPs_all_roles": round(gemm_tf, 2)},
+           # the stride-1 convs with >= 32 input channels run on the bf16 matrix pipe as six bf16 piece products per fp32 product
+           # (k_conv_bx): the peak that bounds them is the dense bf16 MFMA peak / 6, in fp32-equivalent TFLOP/s
            "vqgan": {"decode_TFLOPs": round(252.7e9 * B / split["vq_decode_s"] * 1e-12, 1),
-                     "encode_TFLOPs": round(140.5e9 * B / split["vq_encode_s"] * 1e-12, 1), "peak": PEAK_F32_MFMA_TF},
+                     "encode_TFLOPs": round(140.5e9 * B / split["vq_encode_s"] * 1e-12, 1),
+                     "pipe": "v_mfma_f32_32x32x16_bf16, 6 piece products per fp32 product (exact 3-way bf16 split)",
+                     "peak": round(PEAK_BF16_MFMA_TF / 6, 1), "peak_fp32_mfma": PEAK_F32_MFMA_TF,
+                     "decode_frac": round(252.7e9 * B / split["vq_decode_s"] * 1e-12 / (PEAK_BF16_MFMA_TF / 6), 3),
+                     "encode_frac": round(140.5e9 * B / split["vq_encode_s"] * 1e-12 / (PEAK_BF16_MFMA_TF / 6), 3)},
            "end_to_end_frac_of_roofline": None,
            "stage_seconds_per_batch": split}
     return out
