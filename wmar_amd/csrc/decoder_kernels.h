@@ -4,6 +4,7 @@
 #include <cstdint>
 
 #include "sampler.h"
+#include "bx_split.h"
 
 namespace wmar {
 
@@ -974,6 +975,234 @@ static int launch_qkvx(const QkvxArgs& q, int MT, int S_in, hipStream_t st) {
     set_error("qkvx: %d row tiles unsupported", MT);
     return WMAR_EINVAL;
 }
+
+// ------------------------------------------------- the same launch on the bf16 matrix pipe (64 rows)
+// k_qkvx with the multiplying waves on v_mfma_f32_32x32x16_bf16 (bx_split.h: six bf16 piece products per fp32 product, fp32
+// accuracy): a chunk of 32 k is 2 x 12 MFMAs of 32 cycles instead of 32 of 64.  The staging waves split x' into its three bf16
+// pieces once per workgroup and write them to LDS in the B-operand layout [step][row tile][piece][lane] (8-byte stores); the
+// multiplying waves read 16-byte operands, keep their fp32 weights (Wq: k_pack_qkvx_bx layout, no extra HBM bytes) in the same
+// 4-chunk ring and split them in registers between the MFMAs.  K slices are cut on 16-k steps.
+static __global__ void k_pack_qkvx_bx(const float* __restrict__ W, const float* __restrict__ gamma, float4* __restrict__ Wq, int N, int K,
+                                      int tile_off) {
+    // Wq[tile][ku][half][lane] float4: lane holds W[n = 32 tile + lane % 32][k = 16 ku + 8 (lane / 32) + 4 half + 0..3] * gamma[k]
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int KU = K / 16;
+    if (idx >= (long long)(N / 32) * KU * 128) return;
+    const int lane = (int)(idx & 63), hf = (int)((idx >> 6) & 1);
+    const long long r = idx >> 7;
+    const int ku = (int)(r % KU), tile = (int)(r / KU);
+    const int k = ku * 16 + 8 * (lane >> 5) + 4 * hf;
+    const float* p = W + (long long)(tile * 32 + (lane & 31)) * K + k;
+    float4 v = make_float4(p[0], p[1], p[2], p[3]);
+    if (gamma) { v.x *= gamma[k]; v.y *= gamma[k + 1]; v.z *= gamma[k + 2]; v.w *= gamma[k + 3]; }
+    Wq[idx + (long long)tile_off * KU * 128] = v;
+}
+
+template <int S_IN>
+__global__ __launch_bounds__(512) void k_qkvx_bx(QkvxArgs a) {
+    constexpr int MTW = 2;
+    __shared__ __attribute__((aligned(16))) u32x4 xq[2][2][MTW][3][64];      // [buffer][step][row tile][piece][lane]
+    __shared__ double red[4][MTW][32][2];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5;
+    const int G = a.NT >> 2;
+    const int j = (int)(blockIdx.x & 7) * a.cap + (int)(blockIdx.x >> 3);
+    if (j >= G * a.S) return;
+    const int s = j / G, g = j - s * G;
+    const int KU = a.KB >> 1;                                       // 16-k steps; slices are cut on steps
+    const int kb0 = 2 * (int)((unsigned)s * (unsigned)KU / (unsigned)a.S);
+    const int kb1 = 2 * (int)((unsigned)(s + 1) * (unsigned)KU / (unsigned)a.S);
+    const int nkb = kb1 - kb0, nch = (nkb + QX_CK - 1) / QX_CK;
+    const bool keeper = g == 0;
+
+    if (w >= 4) {
+        // ------------------------------------------------------------------------------------------ staging waves
+        const int sw = w - 4;
+        double sum[MTW], sq[MTW];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) { sum[i] = 0.0; sq[i] = 0.0; }
+        float4 xvA[MTW], bbA, slA[S_IN > 0 ? S_IN : 1][MTW];
+        float4 xvB[MTW], bbB, slB[S_IN > 0 ? S_IN : 1][MTW];
+        int skbA = 0, skbB = 0;
+#define WMAR_QX_ISSUE(XV, BB, SL, SKB, C)                                                              \
+    {                                                                                                   \
+        SKB = kb0 + (C) * QX_CK + sw;                                                                   \
+        const int kk = SKB < kb1 ? SKB : kb1 - 1;                                                       \
+        const long long idx = (long long)kk * MTW * 64 + lane;                                          \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i) XV[i] = a.x_in[idx + i * 64];                   \
+        if (S_IN > 0) {                                                                                 \
+            BB = *(const float4*)(a.bias + kk * 8 + 4 * half);                                          \
+            _Pragma("unroll") for (int si = 0; si < S_IN; ++si)                                         \
+                _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                         \
+                    SL[si][i] = a.slabs[(long long)si * a.slab_stride + idx + i * 64];                  \
+        }                                                                                               \
+    }
+// wave sw stages k-block sw of the chunk: step sw / 2, operand lanes m + 32 (sw % 2), this lane's 8 bytes = half
+#define WMAR_QX_FINISH(XV, BB, SL, SKB, BUF)                                                           \
+    if (SKB < kb1) {                                                                                    \
+        const bool short_tile = a.n_hi > 0 && (SKB >> 2) >= a.n_hi;                                     \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i) {                                               \
+            float4 r = XV[i];                                                                           \
+            if (S_IN > 0) {                                                                             \
+                float4 t = SL[0][i];                                                                    \
+                _Pragma("unroll") for (int si = 1; si < S_IN; ++si)                                     \
+                    if (!(si == S_IN - 1 && short_tile)) {                                              \
+                        t.x += SL[si][i].x; t.y += SL[si][i].y; t.z += SL[si][i].z; t.w += SL[si][i].w; \
+                    }                                                                                   \
+                r = make_float4(r.x + (BB.x + t.x), r.y + (BB.y + t.y), r.z + (BB.z + t.z), r.w + (BB.w + t.w)); \
+            }                                                                                           \
+            unsigned h0, m0, l0, h1, m1, l1;                                                            \
+            bx_split2(r.x, r.y, h0, m0, l0);                                                            \
+            bx_split2(r.z, r.w, h1, m1, l1);                                                            \
+            u32x2* d = (u32x2*)&xq[BUF][sw >> 1][i][0][(lane & 31) + 32 * (sw & 1)] + half;             \
+            d[0] = u32x2{h0, h1}; d[128] = u32x2{m0, m1}; d[256] = u32x2{l0, l1};                       \
+            if (keeper) {                                                                               \
+                a.x_out[((long long)SKB * MTW + i) * 64 + lane] = r;                                    \
+                sum[i] += (double)r.x + (double)r.y + (double)r.z + (double)r.w;                        \
+                sq[i] += (double)r.x * r.x + (double)r.y * r.y + (double)r.z * r.z + (double)r.w * r.w; \
+            }                                                                                           \
+        }                                                                                               \
+    }
+        WMAR_QX_ISSUE(xvA, bbA, slA, skbA, 0)
+        WMAR_QX_ISSUE(xvB, bbB, slB, skbB, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        WMAR_QX_FINISH(xvA, bbA, slA, skbA, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        WMAR_QX_ISSUE(xvA, bbA, slA, skbA, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                   // barrier(-1): chunk 0 is in LDS
+        for (int c = 0; c + 1 < nch; c += 2) {
+            WMAR_QX_FINISH(xvB, bbB, slB, skbB, 1)         // chunk c+1
+            __builtin_amdgcn_sched_barrier(0);
+            WMAR_QX_ISSUE(xvB, bbB, slB, skbB, c + 3)
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                               // barrier(c)
+            if (c + 2 >= nch) break;
+            WMAR_QX_FINISH(xvA, bbA, slA, skbA, 0)         // chunk c+2
+            __builtin_amdgcn_sched_barrier(0);
+            WMAR_QX_ISSUE(xvA, bbA, slA, skbA, c + 4)
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                               // barrier(c+1)
+        }
+#undef WMAR_QX_ISSUE
+#undef WMAR_QX_FINISH
+        if (keeper) {
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+                sum[i] += __shfl_xor(sum[i], 32);
+                sq[i] += __shfl_xor(sq[i], 32);
+                if (lane < 32) { red[sw][i][lane][0] = sum[i]; red[sw][i][lane][1] = sq[i]; }
+            }
+            __syncthreads();                               // the multiplying waves meet it after their stores
+            const int t = threadIdx.x - 256;
+            if (t < 32 * MTW) {
+                const int i = t >> 5, r = t & 31;
+                double ts = 0, tss = 0;
+                for (int ww = 0; ww < 4; ++ww) { ts += red[ww][i][r][0]; tss += red[ww][i][r][1]; }
+                double* o = a.stats + ((long long)s * (MTW * 32) + i * 32 + r) * 2;
+                o[0] = ts; o[1] = tss;
+            }
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------------------------------ multiplying waves
+    const int nt = g * 4 + w;
+    f32x16 acc[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // chunk c, slot u: step u / 2, half u % 2 of the weight tile's k-step (kb0 + 4 c) / 2 + u / 2
+    const float4* Wq = a.Wp + ((long long)nt * KU + (kb0 >> 1)) * 128 + lane;
+    float4 w0[QX_CK], w1[QX_CK], w2[QX_CK], w3[QX_CK];
+    u32x4 xfA[2][MTW][3], xfB[2][MTW][3];
+#define WMAR_QX_W(WBUF, C)                                                                             \
+    _Pragma("unroll") for (int u = 0; u < QX_CK; ++u) {                                                 \
+        const int kl = (C) * QX_CK + u;                                                                 \
+        WBUF[u] = ld_nt(Wq + (long long)(kl < nkb ? kl : nkb - 1) * 64);                                \
+    }
+#define WMAR_QX_READ(XF, BUF)                                                                          \
+    _Pragma("unroll") for (int st = 0; st < 2; ++st)                                                    \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                 \
+            _Pragma("unroll") for (int p = 0; p < 3; ++p) XF[st][i][p] = xq[BUF][st][i][p][lane];
+#define WMAR_QX_BF(V) __builtin_bit_cast(bf16x8, V)
+#define WMAR_QX_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
+// one 16-k step: split the step's weights (VALU), twelve MFMAs, the small products first
+#define WMAR_QX_MMA(WBUF, XF, C, ST)                                                                   \
+    if ((C) * QX_CK + 2 * (ST) < nkb) {                                                                 \
+        unsigned h_[4], m_[4], l_[4];                                                                   \
+        bx_split2(WBUF[2 * (ST)].x, WBUF[2 * (ST)].y, h_[0], m_[0], l_[0]);                             \
+        bx_split2(WBUF[2 * (ST)].z, WBUF[2 * (ST)].w, h_[1], m_[1], l_[1]);                             \
+        bx_split2(WBUF[2 * (ST) + 1].x, WBUF[2 * (ST) + 1].y, h_[2], m_[2], l_[2]);                     \
+        bx_split2(WBUF[2 * (ST) + 1].z, WBUF[2 * (ST) + 1].w, h_[3], m_[3], l_[3]);                     \
+        const bf16x8 wh = WMAR_QX_BF((u32x4{h_[0], h_[1], h_[2], h_[3]})), wm = WMAR_QX_BF((u32x4{m_[0], m_[1], m_[2], m_[3]})), \
+                     wl = WMAR_QX_BF((u32x4{l_[0], l_[1], l_[2], l_[3]}));                              \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i) WMAR_QX_MFMA(wl, WMAR_QX_BF(XF[ST][i][0]), acc[i]); \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i) WMAR_QX_MFMA(wh, WMAR_QX_BF(XF[ST][i][2]), acc[i]); \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i) WMAR_QX_MFMA(wm, WMAR_QX_BF(XF[ST][i][1]), acc[i]); \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i) WMAR_QX_MFMA(wm, WMAR_QX_BF(XF[ST][i][0]), acc[i]); \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i) WMAR_QX_MFMA(wh, WMAR_QX_BF(XF[ST][i][1]), acc[i]); \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i) WMAR_QX_MFMA(wh, WMAR_QX_BF(XF[ST][i][0]), acc[i]); \
+    }
+// one chunk: request the weights three chunks ahead, multiply the first step, pass the chunk barrier and read the next chunk's
+// operands, multiply the second step
+#define WMAR_QX_STEP(C, WCUR, WFAR, XCUR, XNEXT, BUFNEXT)                                              \
+    WMAR_QX_W(WFAR, (C) + 3)                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    WMAR_QX_MMA(WCUR, XCUR, C, 0)                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if ((C) + 1 < nch) {                                                                                \
+        __syncthreads();                                                                                \
+        WMAR_QX_READ(XNEXT, BUFNEXT)                                                                    \
+    }                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    WMAR_QX_MMA(WCUR, XCUR, C, 1)                                                                       \
+    __builtin_amdgcn_sched_barrier(0);
+
+    WMAR_QX_W(w0, 0)
+    WMAR_QX_W(w1, 1)
+    WMAR_QX_W(w2, 2)
+    __syncthreads();                                       // barrier(-1)
+    WMAR_QX_READ(xfA, 0)
+    for (int c = 0; c < nch; c += 4) {
+        WMAR_QX_STEP(c, w0, w3, xfA, xfB, 1)
+        if (c + 1 >= nch) break;
+        WMAR_QX_STEP(c + 1, w1, w0, xfB, xfA, 0)
+        if (c + 2 >= nch) break;
+        WMAR_QX_STEP(c + 2, w2, w1, xfA, xfB, 1)
+        if (c + 3 >= nch) break;
+        WMAR_QX_STEP(c + 3, w3, w2, xfB, xfA, 0)
+    }
+#undef WMAR_QX_W
+#undef WMAR_QX_READ
+#undef WMAR_QX_MMA
+#undef WMAR_QX_MFMA
+#undef WMAR_QX_BF
+#undef WMAR_QX_STEP
+    // one split-K piece per wave, straight from the accumulators (already the packed layout of the consumer)
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+            a.out[(long long)s * a.out_stride + ((long long)(nt * 4 + q4) * MTW + i) * 64 + lane] =
+                make_float4(acc[i][q4 * 4 + 0], acc[i][q4 * 4 + 1], acc[i][q4 * 4 + 2], acc[i][q4 * 4 + 3]);
+    if (keeper) __syncthreads();
+}
+
+static int launch_qkvx_bx(const QkvxArgs& q, int S_in, hipStream_t st) {
+    const dim3 grid((unsigned)(8 * q.cap));
+    switch (S_in) {
+#define WMAR_QX_CASE(N) case N: hipLaunchKernelGGL((k_qkvx_bx<N>), grid, dim3(512), 0, st, q); break;
+        WMAR_QX_CASE(0) WMAR_QX_CASE(1) WMAR_QX_CASE(2) WMAR_QX_CASE(3) WMAR_QX_CASE(4)
+        WMAR_QX_CASE(5) WMAR_QX_CASE(6) WMAR_QX_CASE(7) WMAR_QX_CASE(8)
+#undef WMAR_QX_CASE
+        default: set_error("qkvx_bx: bad slab count %d", S_in); return WMAR_EINVAL;
+    }
+    return launch_status("k_qkvx_bx");
+}
+
 
 // --------------------------------------------------------------------- decode attention
 // One wave per (sequence, head).  K/V rows are hd floats; LPR = hd/4 lanes cover a row with

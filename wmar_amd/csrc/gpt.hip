@@ -31,6 +31,7 @@ struct LayerW {
     float4 *wqkv, *wproj, *wfc1, *wfc2;
     float4* wfc1x16 = nullptr;   // FC1 in k_fc1x's 24-column packing (null: shape not eligible)
     float2* wfc1x8 = nullptr;
+    float4* wqkvx_bx = nullptr;  // QKV weights in k_qkvx_bx's 16-k step order (null: shape not eligible)
     float *bqkv, *bproj, *bfc1, *bfc2, *cqkv, *cfc1;
 };
 
@@ -78,6 +79,7 @@ struct wmar_gpt {
     int att_phase(int kv) const { return kv <= att_t1 ? 0 : (kv <= att_t2 ? 1 : 2); }
     static int phase_waves(int ph) { return ph == 0 ? 1 : (ph == 1 ? 2 : 4); }
     int timing = 0;
+    bool no_bx = false;           // dev knob WMAR_NO_BX: keep the fp32-MFMA k_qkvx
     int force_s[3] = {0, 0, 0};   // tuning knobs: WMAR_S_QKV / WMAR_S_PROJ / WMAR_S_FC2
     double step_ms = 0.0;
     // per-launch event timing (eager mode only)
@@ -235,7 +237,9 @@ struct StepPlan {
         q.KB = KBD; q.NT = 3 * D / 32; q.S = S_qx;
         q.cap = ((q.NT / 4) * q.S + 7) / 8;
         g->span_begin(WMAR_T_QKV, st);
-        const int rc = launch_qkvx(q, MT, S_in, st);
+        int rc;
+        if (MT == 2 && w.wqkvx_bx && !g->no_bx) { q.Wp = w.wqkvx_bx; rc = launch_qkvx_bx(q, S_in, st); }   // 33..64 rows: bf16 matrix pipe
+        else rc = launch_qkvx(q, MT, S_in, st);
         g->span_end(st);
         xcur = xout;
         return rc;
@@ -396,6 +400,7 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
             const char* e = getenv(names_s[i]);
             if (e) g->force_s[i] = atoi(e) > MAX_SLABS ? MAX_SLABS : atoi(e);
         }
+        g->no_bx = getenv("WMAR_NO_BX") != nullptr;
     }
 #endif
     int rc = WMAR_OK;
@@ -434,6 +439,17 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
         TRY(pack(qw, w.wqkv, D, D, 0, st, l1w));
         TRY(pack(kw, w.wqkv, D, D, D / 32, st, l1w));
         TRY(pack(vw, w.wqkv, D, D, 2 * D / 32, st, l1w));
+        if (g->MTmax >= 2 && D % 16 == 0 && (3 * D / 32) % 4 == 0) {
+            auto pack_bx = [&](const float* W, int tile_off) -> int {
+                const long long total = (long long)(D / 32) * (D / 16) * 128;
+                hipLaunchKernelGGL(k_pack_qkvx_bx, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, l1w, w.wqkvx_bx, D, D, tile_off);
+                return launch_status("k_pack_qkvx_bx");
+            };
+            TRY(g->alloc(&w.wqkvx_bx, (size_t)3 * D * D / 4));
+            TRY(pack_bx(qw, 0));
+            TRY(pack_bx(kw, D / 32));
+            TRY(pack_bx(vw, 2 * D / 32));
+        }
         TRY(g->alloc(&w.bqkv, (size_t)3 * D));
         TRY(fold_bias(qw, qb, l1b, w.bqkv, D, D, st));
         TRY(fold_bias(kw, kb, l1b, w.bqkv + D, D, D, st));
