@@ -32,4 +32,24 @@ __device__ __forceinline__ void bx_split2(float a, float b, unsigned& h, unsigne
     l = bx_pk(sa, sb);
 }
 
+// Activation planes Xq[ku][mt][piece][lane] (16 bytes = 8 bf16 per lane): lane holds row m = 32 mt + lane % 32, features
+// k = 16 ku + 8 (lane / 32) + 0..7 -- the B operand of v_mfma_f32_32x32x16_bf16.  A producer thread owns four consecutive
+// features (k = 8 kb + 4 hf + 0..3, the float4 of the packed fp32 layout) and stores its half of the 16 bytes of each piece.
+__device__ __forceinline__ void bx_store_planes4(u32x4* __restrict__ Xq, int MT, int kb, int hf, int mt, int m32, const float4 v) {
+    unsigned h0, h1, m0, m1, l0, l1;
+    bx_split2(v.x, v.y, h0, m0, l0);
+    bx_split2(v.z, v.w, h1, m1, l1);
+    u32x2* p = (u32x2*)(Xq + ((long long)((kb >> 1) * MT + mt) * 3) * 64 + m32 + 32 * (kb & 1)) + hf;
+    p[0] = u32x2{h0, h1}; p[128] = u32x2{m0, m1}; p[256] = u32x2{l0, l1};
+}
+__device__ __forceinline__ void bx_split8(const float4 a, const float4 b, bf16x8& h, bf16x8& m, bf16x8& l) {
+    unsigned h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
+    bx_split2(a.x, a.y, h0, m0, l0);
+    bx_split2(a.z, a.w, h1, m1, l1);
+    bx_split2(b.x, b.y, h2, m2, l2);
+    bx_split2(b.z, b.w, h3, m3, l3);
+    const u32x4 uh = {h0, h1, h2, h3}, um = {m0, m1, m2, m3}, ul = {l0, l1, l2, l3};
+    h = __builtin_bit_cast(bf16x8, uh); m = __builtin_bit_cast(bf16x8, um); l = __builtin_bit_cast(bf16x8, ul);
+}
+
 }  // namespace wmar

@@ -980,9 +980,9 @@ static int launch_qkvx(const QkvxArgs& q, int MT, int S_in, hipStream_t st) {
 // k_qkvx with the multiplying waves on v_mfma_f32_32x32x16_bf16 (bx_split.h: six bf16 piece products per fp32 product, fp32
 // accuracy): a chunk of 32 k is 2 x 12 MFMAs of 32 cycles instead of 32 of 64.  The staging waves split x' into its three bf16
 // pieces once per workgroup and write them to LDS in the B-operand layout [step][row tile][piece][lane] (8-byte stores); the
-// multiplying waves read 16-byte operands, keep their fp32 weights (Wq: k_pack_qkvx_bx layout, no extra HBM bytes) in the same
+// multiplying waves read 16-byte operands, keep their fp32 weights (Wq: k_pack_bx layout, no extra HBM bytes) in the same
 // 4-chunk ring and split them in registers between the MFMAs.  K slices are cut on 16-k steps.
-static __global__ void k_pack_qkvx_bx(const float* __restrict__ W, const float* __restrict__ gamma, float4* __restrict__ Wq, int N, int K,
+static __global__ void k_pack_bx(const float* __restrict__ W, const float* __restrict__ gamma, float4* __restrict__ Wq, int N, int K,
                                       int tile_off) {
     // Wq[tile][ku][half][lane] float4: lane holds W[n = 32 tile + lane % 32][k = 16 ku + 8 (lane / 32) + 4 half + 0..3] * gamma[k]
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1204,6 +1204,125 @@ static int launch_qkvx_bx(const QkvxArgs& q, int S_in, hipStream_t st) {
 }
 
 
+// ------------------------------------------------- plain split-K GEMM on the bf16 matrix pipe (64 rows; the output projection)
+// out[64 x N] = X W^T with X given as bf16 pieces (planes [K/16][2][3][64], written by the producer: bx_store_planes4) and W in
+// fp32 (k_pack_bx order), split in registers.  Workgroup = NT column tiles of 32 x one K slice of 384 (S = K / 384); its four waves
+// take 96 k each (PER = 6 steps of 16) for all 64 rows, and meet in LDS in a fixed order.  Slab s = raw partial sums of slice s in
+// the packed fp32 layout -- what k_resid_stats consumes.  A wave keeps ONE step of weights and of activation pieces in flight
+// beyond the one it computes on: more requests per CU than that queue at the memory pipeline and block the wave's in-order
+// issue, MFMAs included (scripts/stream_profile.hip, scripts/bx6_bench.hip).
+struct BxArgs {
+    const float4* Wq;          // k_pack_bx layout
+    const u32x4* Xq;           // activation planes [K/16][2][3][64] (64 rows)
+    float4* out;               // slab s at out + s * slab_stride, packed [N/8][2][64]
+    long long slab_stride;     // float4 units
+    int KU;                    // K / 16
+    int S;                     // K slices: KU == 4 * PER * S
+};
+
+#define WMAR_BX_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
+
+template <int NT, int PER>
+__global__ __launch_bounds__(256) void k_bx(BxArgs a) {
+    __shared__ __attribute__((aligned(16))) float4 red[4][NT * 8][64];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // slice = id % S: with S a multiple of 4 every XCD (id % 8) works on one or two K slices and keeps only those in its L2
+    const int grp = (int)blockIdx.x / a.S, ks = (int)blockIdx.x % a.S;
+    const int u0 = (ks * 4 + w) * PER;
+    f32x16 acc[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.f;
+    const float4* wp = a.Wq + ((long long)grp * NT * a.KU + u0) * 128 + lane;
+    const long long wt = (long long)a.KU * 128;     // next column tile
+    const u32x4* xp = a.Xq + (long long)u0 * 6 * 64 + lane;
+    float4 wr[NT][2];
+    u32x4 xr[6];
+#define WMAR_BX_LOADW(U)                                                                           \
+    { _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                             \
+        wr[t][0] = ld_nt(wp + t * wt + (long long)(U) * 128);                                      \
+        wr[t][1] = ld_nt(wp + t * wt + (long long)(U) * 128 + 64); } }
+#define WMAR_BX_LOADX(U)                                                                           \
+    { _Pragma("unroll") for (int q = 0; q < 6; ++q) xr[q] = xp[(long long)(U) * 384 + q * 64]; }
+    WMAR_BX_LOADW(0);
+    WMAR_BX_LOADX(0);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 ph[2][NT], pm[2][NT], pl[2][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bx_split8(wr[t][0], wr[t][1], ph[0][t], pm[0][t], pl[0][t]);
+    if (1 < PER) WMAR_BX_LOADW(1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int c = j & 1, n = c ^ 1;
+        // the NEXT step's weights are split (VALU) between this step's MFMAs; their registers are refilled at once
+        if (j + 1 < PER) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bx_split8(wr[t][0], wr[t][1], ph[n][t], pm[n][t], pl[n][t]);
+            if (j + 2 < PER) WMAR_BX_LOADW(j + 2);
+        }
+        bf16x8 x[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) x[q] = __builtin_bit_cast(bf16x8, xr[q]);
+        // x[3 mt + piece]; the small products first
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { WMAR_BX_MFMA(pl[c][t], x[0], acc[t][0]); WMAR_BX_MFMA(pl[c][t], x[3], acc[t][1]); }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { WMAR_BX_MFMA(ph[c][t], x[2], acc[t][0]); WMAR_BX_MFMA(ph[c][t], x[5], acc[t][1]); }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { WMAR_BX_MFMA(pm[c][t], x[1], acc[t][0]); WMAR_BX_MFMA(pm[c][t], x[4], acc[t][1]); }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { WMAR_BX_MFMA(pm[c][t], x[0], acc[t][0]); WMAR_BX_MFMA(pm[c][t], x[3], acc[t][1]); }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { WMAR_BX_MFMA(ph[c][t], x[1], acc[t][0]); WMAR_BX_MFMA(ph[c][t], x[4], acc[t][1]); }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { WMAR_BX_MFMA(ph[c][t], x[0], acc[t][0]); WMAR_BX_MFMA(ph[c][t], x[3], acc[t][1]); }
+        if (j + 1 < PER) WMAR_BX_LOADX(j + 1);
+#pragma unroll
+        for (int i = 0; i < 12 * NT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            if (i % 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef WMAR_BX_LOADW
+#undef WMAR_BX_LOADX
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                red[w][(t * 2 + i) * 4 + g][lane] = make_float4(acc[t][i][4 * g], acc[t][i][4 * g + 1], acc[t][i][4 * g + 2], acc[t][i][4 * g + 3]);
+    __syncthreads();
+    // wave w sums rows w, w + 4, ... of the NT * 8 (tile, row tile, register group) rows over the four K quarters, in fixed order
+    float4* out = a.out + (long long)ks * a.slab_stride;
+#pragma unroll
+    for (int r = 0; r < NT * 2; ++r) {
+        const int row = r * 4 + w, t = row >> 3, i = (row >> 2) & 1, g = row & 3;
+        float4 v = red[0][row][lane];
+#pragma unroll
+        for (int o = 1; o < 4; ++o) { const float4 q = red[o][row][lane]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+        out[((long long)((grp * NT + t) * 4 + g) * 2 + i) * 64 + lane] = v;
+    }
+}
+
+constexpr int BX_PER = 6;              // 16-k steps per wave: K slice = 4 waves x 6 x 16 = 384
+constexpr int BX_KSLICE = 4 * BX_PER * 16;
+// N must be a multiple of 32 * NT, K of 384; 64 rows (MT = 2)
+template <int NT>
+static int launch_bx(const BxArgs& a, int N, hipStream_t st) {
+    hipLaunchKernelGGL((k_bx<NT, BX_PER>), dim3((unsigned)(N / (32 * NT) * a.S)), dim3(256), 0, st, a);
+    return launch_status("k_bx");
+}
+
+
+
 // --------------------------------------------------------------------- decode attention
 // One wave per (sequence, head).  K/V rows are hd floats; LPR = hd/4 lanes cover a row with
 // float4s and RPI = 64/LPR rows are read per wave-wide load (1 KiB, coalesced).
@@ -1224,6 +1343,7 @@ struct AttnArgs {
     float* kcache;             // [B][H][Tmax][hd] (this layer)
     float* vcache;
     float4* y;                 // packed [KB][MT][64]
+    u32x4* yq;                 // nullable: the same rows as bf16 pieces for a k_bx output projection (then y is not written)
     const int* pos_dev;
     int D, H, Tmax, MT;
     float scale;
@@ -1470,7 +1590,9 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
         const int k = h * HD + sub * 4;
         const int kb = k >> 3, hf = (k >> 2) & 1;
         const int mt = b >> 5;
-        a.y[((long long)kb * a.MT + mt) * 64 + (b & 31) + 32 * hf] = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+        const float4 yv = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+        if (a.yq) bx_store_planes4(a.yq, a.MT, kb, hf, mt, b & 31, yv);
+        else a.y[((long long)kb * a.MT + mt) * 64 + (b & 31) + 32 * hf] = yv;
     }
 #ifdef WMAR_ATT_TRACE
     if (a.trace && threadIdx.x == 0) {

@@ -32,6 +32,7 @@ struct LayerW {
     float4* wfc1x16 = nullptr;   // FC1 in k_fc1x's 24-column packing (null: shape not eligible)
     float2* wfc1x8 = nullptr;
     float4* wqkvx_bx = nullptr;  // QKV weights in k_qkvx_bx's 16-k step order (null: shape not eligible)
+    float4* wproj_bx = nullptr;  // output projection in k_pack_bx order for k_bx (null: shape not eligible)
     float *bqkv, *bproj, *bfc1, *bfc2, *cqkv, *cfc1;
 };
 
@@ -45,6 +46,7 @@ struct wmar_gpt {
     float4* whead = nullptr;
     // workspaces
     float4 *x = nullptr, *x2 = nullptr, *y = nullptr, *hbuf = nullptr, *slabs = nullptr, *qkv_slabs = nullptr;
+    u32x4* yq = nullptr;           // attention output as bf16 pieces (k_bx output projection; 64-row steps)
     float* qbuf = nullptr;
     double* stats = nullptr;
     double* stats_q = nullptr;   // [QKV_SLABS_MAX][Mpad][2]: LN1 row sums per K slice, written by k_qkvx
@@ -165,6 +167,7 @@ struct StepPlan {
     // fused residual fold + QKV projection (k_qkvx): column groups x K slices; 0 = not applicable to this shape (k_gemm path)
     int S_qx = 0;
     float4* xcur = nullptr;   // residual stream buffer the next launch reads (the fused fold ping-pongs between x and x2)
+    bool proj_bx = false;     // 33..64 rows, n_embd a multiple of 384: output projection as k_bx on the attention's bf16 pieces
 
     StepPlan(wmar_gpt* g_, int64_t B_, const StepIO& io_, hipStream_t st_) : g(g_), B(B_), io(io_), st(st_) {
         MT = mt_for(B); D = g->D; KBD = D / 8; KBF = 4 * D / 8; nch = stat_chunks(KBD);
@@ -195,6 +198,8 @@ struct StepPlan {
             if (S > KBD / QX_CK) S = KBD / QX_CK;
             if (S >= 1) S_qx = S;
         }
+        proj_bx = MT == 2 && g->yq && g->layers[0].wproj_bx && !g->no_bx && g->force_s[1] <= 0;
+        if (proj_bx) S_proj = D / BX_KSLICE;
     }
     int split_for(int NT, int KB) const { return pick_split(MT % 2 == 0 ? NT * (MT / 2) : NT * MT, KB, 4); }
     GemmArgs base() const {
@@ -263,7 +268,7 @@ struct StepPlan {
         if (S_qx > 0) { t.S = S_qx; t.stats = g->stats_q; t.n_chunks = S_qx; }
         else { t.S = S_qkv; t.stats = g->stats; t.n_chunks = nch; }
         t.c1 = w.cqkv; t.bias = w.bqkv;
-        t.kcache = g->kcache + l * lstride; t.vcache = g->vcache + l * lstride; t.y = g->y; t.pos_dev = g->pos_dev;
+        t.kcache = g->kcache + l * lstride; t.vcache = g->vcache + l * lstride; t.y = g->y; t.yq = proj_bx ? g->yq : nullptr; t.pos_dev = g->pos_dev;
         t.D = D; t.H = g->H; t.Tmax = g->Tmax; t.MT = MT; t.scale = 1.0f / sqrtf((float)g->hd);
         int nwa = g->att_nw;   // chosen per phase by the caller (generate / profile_role)
 #ifdef WMAR_DEV_KNOBS
@@ -288,6 +293,14 @@ struct StepPlan {
     }
     // attention output projection (split-K slabs; bias + residual folded by the next resid())
     int proj(int l) {
+        if (proj_bx) {
+            BxArgs x{};
+            x.Wq = g->layers[l].wproj_bx; x.Xq = g->yq; x.out = g->slabs; x.slab_stride = act; x.KU = D / 16; x.S = D / BX_KSLICE;
+            g->span_begin(WMAR_T_PROJ, st);
+            const int rc = launch_bx<1>(x, D, st);
+            g->span_end(st);
+            return rc;
+        }
         GemmArgs p = base();
         p.Wp = g->layers[l].wproj; p.Xp = g->y; p.KB = KBD; p.NT = D / 32;
         p.out_packed = g->slabs; p.slab_stride = act;
@@ -442,8 +455,8 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
         if (g->MTmax >= 2 && D % 16 == 0 && (3 * D / 32) % 4 == 0) {
             auto pack_bx = [&](const float* W, int tile_off) -> int {
                 const long long total = (long long)(D / 32) * (D / 16) * 128;
-                hipLaunchKernelGGL(k_pack_qkvx_bx, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, l1w, w.wqkvx_bx, D, D, tile_off);
-                return launch_status("k_pack_qkvx_bx");
+                hipLaunchKernelGGL(k_pack_bx, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, l1w, w.wqkvx_bx, D, D, tile_off);
+                return launch_status("k_pack_bx");
             };
             TRY(g->alloc(&w.wqkvx_bx, (size_t)3 * D * D / 4));
             TRY(pack_bx(qw, 0));
@@ -461,6 +474,14 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
         TRY(g->alloc(&w.wproj, (size_t)D * D / 4));
         TRY(pack(pw, w.wproj, D, D, 0, st));
         TRY(copy_vec(g, &w.bproj, pb, D, st));
+        if (g->MTmax >= 2 && D % BX_KSLICE == 0 && D / BX_KSLICE <= MAX_SLABS) {
+            const long long total = (long long)(D / 32) * (D / 16) * 128;
+            TRY(g->alloc(&w.wproj_bx, (size_t)D * D / 4));
+            if (rc == WMAR_OK) {
+                hipLaunchKernelGGL(k_pack_bx, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pw, (const float*)nullptr, w.wproj_bx, D, D, 0);
+                rc = launch_status("k_pack_bx");
+            }
+        }
         TRY(g->alloc(&w.wfc1, (size_t)4 * D * D / 4));
         TRY(pack(f1w, w.wfc1, 4 * D, D, 0, st, l2w));
         if ((4 * D) % 24 == 0 && (D / 16) % 16 == 0 && g->MTmax >= 2) {
@@ -489,6 +510,7 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
     TRY(g->alloc(&g->hbuf, Mpad * 4 * D / 4));
     TRY(g->alloc(&g->slabs, (size_t)MAX_SLABS * Mpad * D / 4));
     TRY(g->alloc(&g->qkv_slabs, (size_t)MAX_SLABS * Mpad * 3 * D / 4));
+    if (g->MTmax >= 2 && D % BX_KSLICE == 0) TRY(g->alloc(&g->yq, (size_t)D / 16 * 2 * 3 * 64));
     TRY(g->alloc(&g->qbuf, Mpad * D));
     TRY(g->alloc(&g->stats, (size_t)STAT_CHUNKS_MAX * Mpad * 2));
     TRY(g->alloc(&g->stats_q, (size_t)QKV_SLABS_MAX * Mpad * 2));
@@ -510,6 +532,7 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
         if (e == hipSuccess) e = hipMemsetAsync(g->past, 0, (size_t)g->Bmax * (g->Tmax + 1) * 8, st);
         if (e == hipSuccess) e = hipMemsetAsync(g->y, 0, Mpad * D * 4, st);
         if (e == hipSuccess) e = hipMemsetAsync(g->qbuf, 0, Mpad * D * 4, st);
+        if (e == hipSuccess && g->yq) e = hipMemsetAsync(g->yq, 0, (size_t)D / 16 * 2 * 3 * 64 * 16, st);   // rows past the batch are never written
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->cap_stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreate(&g->ev0);
         if (e == hipSuccess) e = hipEventCreate(&g->ev1);
