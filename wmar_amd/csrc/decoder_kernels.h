@@ -1399,40 +1399,41 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
     // whole cache up to 64 / 128 / 256 rows streams while q/k/v are finished); otherwise one, the second from inside the loop.
     // (Measured dead end: clamping the first chunk to the cache's capacity instead of its fill, so that its loads need not wait
     // for the scalar load of the position, saves 1.3 us at 64 rows and costs 3 us below 32 rows -- stale rows are then streamed.)
+    // The prologue's loads go FIRST: loads return in issue order, so behind 16 KiB of cache rows per wave the QKV pieces would
+    // arrive only after the chip-wide burst of first chunks has drained (~4 us); ahead of it they are back in ~1.5 us and q, k, v
+    // are finished while the first chunk is still in flight.
+    // every load of the prologue is issued before the first wait: LN partial sums (one chunk per
+    // lane), the QKV slab(s), the folded-LN row sums and the bias (16 lanes each)
+    const int Mpad = a.MT * 32;
+    const int mt = b >> 5;
+    double sm = 0, sq = 0;
+    double2 st0 = make_double2(0.0, 0.0);
+    if (w == 0 && a.mode == 0 && lane < a.n_chunks) st0 = *(const double2*)(a.stats + ((long long)lane * Mpad + b) * 2);
+    // The S split-K pieces of this head's 3 x hd columns are spread over the wave's RPI row groups (piece p is fetched by
+    // group p % RPI), so that a lane holds at most PMAX pieces: all loads are still in flight together, without 3 x 8
+    // float4 registers per lane (the kernel's occupancy is set by its registers).  The partial sums meet in a fixed
+    // xor-butterfly over the groups: the summation order depends on S only.
+    constexpr int PMAX = (QKV_SLABS_MAX + RPI - 1) / RPI;
+    float4 sl[3][PMAX], cc[3], bb[3];
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+        const int n = which * a.D + h * HD + sub * 4;          // first of this lane's 4 columns
+        const long long idx = ((long long)(n >> 3) * a.MT + mt) * 64 + (b & 31) + 32 * ((n >> 2) & 1);
+#pragma unroll
+        for (int pi = 0; pi < PMAX; ++pi) {
+            const int pc = rsel + pi * RPI;
+            sl[which][pi] = (w == 0 && pc < a.S) ? a.qkv_slabs[(long long)pc * a.slab_stride + idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (w == 0 && rsel == 0) {
+            cc[which] = a.mode == 0 ? *(const float4*)(a.c1 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bb[which] = *(const float4*)(a.bias + n);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (w < nchunk) { WMAR_ATT_LOAD(kA, vA, w) }
     if (PF2 && w + NWA < nchunk) { WMAR_ATT_LOAD(kB, vB, w + NWA) }
     __builtin_amdgcn_sched_barrier(0);
-    // ---- wave 0 finishes this head's q, k, v for the new token from the QKV slab(s) and hands
-    // them to the other waves through LDS.  Loads are issued by as few lanes as possible: a
-    // wave-wide load of one shared address still costs the address path a full 64-lane pass.
     if (w == 0) {
-        // every load of the prologue is issued before the first wait: LN partial sums (one chunk per
-        // lane), the QKV slab(s), the folded-LN row sums and the bias (16 lanes each)
-        const int Mpad = a.MT * 32;
-        const int mt = b >> 5;
-        double sm = 0, sq = 0;
-        double2 st0 = make_double2(0.0, 0.0);
-        if (a.mode == 0 && lane < a.n_chunks) st0 = *(const double2*)(a.stats + ((long long)lane * Mpad + b) * 2);
-        // The S split-K pieces of this head's 3 x hd columns are spread over the wave's RPI row groups (piece p is fetched by
-        // group p % RPI), so that a lane holds at most PMAX pieces: all loads are still in flight together, without 3 x 8
-        // float4 registers per lane (the kernel's occupancy is set by its registers).  The partial sums meet in a fixed
-        // xor-butterfly over the groups: the summation order depends on S only.
-        constexpr int PMAX = (QKV_SLABS_MAX + RPI - 1) / RPI;
-        float4 sl[3][PMAX], cc[3], bb[3];
-#pragma unroll
-        for (int which = 0; which < 3; ++which) {
-            const int n = which * a.D + h * HD + sub * 4;          // first of this lane's 4 columns
-            const long long idx = ((long long)(n >> 3) * a.MT + mt) * 64 + (b & 31) + 32 * ((n >> 2) & 1);
-#pragma unroll
-            for (int pi = 0; pi < PMAX; ++pi) {
-                const int pc = rsel + pi * RPI;
-                sl[which][pi] = pc < a.S ? a.qkv_slabs[(long long)pc * a.slab_stride + idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            if (rsel == 0) {
-                cc[which] = a.mode == 0 ? *(const float4*)(a.c1 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-                bb[which] = *(const float4*)(a.bias + n);
-            }
-        }
 #ifdef WMAR_ATT_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tr[1] = __builtin_amdgcn_s_memtime();
