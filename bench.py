@@ -209,10 +209,10 @@ def gpu_analysis(model, wm, extra, cond, args, world, log):
     attn_bytes = 2.0 * B * D * 4 * kv_avg                  # K and V rows of kv_avg cached tokens for every (sequence, head)
     share = {k: avg_us[k] * per_step[k] for k in per_step}
     tot = sum(share.values())
-    names = {"qkv": "k_qkvx<2,6> residual fold + LN1 statistics + QKV 1536->4608 (252 workgroups, split-K pieces)",
+    names = {"qkv": "k_qkvx_bx<6> residual fold + LN1 statistics + QKV 1536->4608 (252 workgroups, split-K pieces; bf16 matrix pipe, 6 piece products per fp32 product)",
              "attn": "k_attn_decode<64,1> decode attention, fp32 KV cache",
              "fc1": "k_fc1x LN2 + FC1 1536->6144 + bias + GELU (256 workgroups x 24 columns)", "fc2": "k_gemm<2,4,EPI_PACKED> 6144->1536 split-K (FC2)",
-             "proj": "k_gemm<2,4,EPI_PACKED> 1536->1536 split-K (proj)", "head": "k_gemm<2,4,EPI_LOGITS,LN> 1536->16384 (head)",
+             "proj": "k_bx<1,6> 1536->1536 split-K (proj; bf16 matrix pipe, 6 piece products per fp32 product)", "head": "k_gemm<2,4,EPI_LOGITS,LN> 1536->16384 (head)",
              "resid": "k_resid_stats residual fold + LN2 statistics"}
     roles = {}
     for k in per_step:

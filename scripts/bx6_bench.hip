@@ -1,7 +1,7 @@
 // Dev tool: fp32 GEMM on the bf16 matrix pipe.  Every fp32 operand is split EXACTLY into three bf16 pieces (w = h + m + l, 8 + 8 + 8
 // significand bits); the six products of combined order <= 2 (hh, hm, mh, hl, lh, mm) are accumulated in fp32 by
 // v_mfma_f32_32x32x16_bf16 (32 cycles for 32x32x16, against 8 x 64 for the fp32-input MFMA).  The dropped products (ml, lm, ll) are
-// below 2^-26 of |x w|, under the fp32 rounding of the product itself.  Weights stay fp32 in HBM (no extra bytes) and are split in
+// at most 2^-24 of |x w| (worst case; typically 2^-27): no more than the fp32 rounding of the product itself.  Weights stay fp32 in HBM (no extra bytes) and are split in
 // registers; the activation arrives pre-split from its producer.
 // Shape: out[64 x N] = X[64 x K] W[N x K]^T, N = 6144, K = 1536 (FC1 of the Taming GPT), raw sums, against an fp64 host reference.
 #include <hip/hip_runtime.h>

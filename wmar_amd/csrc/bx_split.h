@@ -1,8 +1,9 @@
 // fp32 operands for the bf16 matrix pipe: x = h + m + l EXACTLY, three bf16 pieces of 8 significand bits each (round-to-nearest
-// pieces: |m| <= 2^-9 |x|, |l| <= 2^-18 |x|; exact for every finite fp32 whose low pieces do not underflow, |x| > 2^-100).
+// pieces: |m| <= 2^-8 |x|, |l| <= 2^-17 |x|; exact for every finite fp32 whose low pieces do not underflow, |x| > 2^-100).
 // A product w x is then accumulated in fp32 by v_mfma_f32_32x32x16_bf16 as the six piece products of combined order <= 2,
 //     wl xh + wh xl + wm xm + (wm xh + wh xm) + wh xh ,
-// the dropped ones (wm xl, wl xm, wl xl) being below 2^-26 |w x|, under the rounding of the fp32 product itself: an fp32
+// the dropped ones (wm xl, wl xm, wl xl) being at most 2^-24 |w x| (worst case, typically 2^-27; tests/test_bx_split_math.py) --
+// no more than the rounding of the fp32 product itself: an fp32
 // contraction at 6 x 32 cycles per 32 x 32 x 16 instead of the 8 x 64 of v_mfma_f32_32x32x2_f32 (the fp32-input MFMA runs at the
 // fp32 VECTOR rate).  Measured against fp64 (scripts/bx6_bench.hip, K = 1536..6144): max error 0.06-0.15x that of an fp32 fma chain
 // over the same K, because the MFMA rounds once per 16 products.  An infinite input gives NaN (inf - inf in the split).
