@@ -55,9 +55,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     jobs = []
     for src, flags in srcs:
         obj = os.path.join(objdir, src + ".o")
-        stale = force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src))
+        cmd = [hipcc] + COMMON + flags + dev + ["-c", os.path.join(CSRC, src), "-o", obj]
+        stamp = obj + ".cmd"       # the command line the object was built with: a change of flags (dev knobs) rebuilds it
+        same_cmd = os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
+        stale = force or not same_cmd or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src))
         if stale:
-            jobs.append((src, [hipcc] + COMMON + flags + dev + ["-c", os.path.join(CSRC, src), "-o", obj]))
+            jobs.append((src, cmd))
 
     def run(job):
         src, cmd = job
@@ -68,6 +71,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
         if verbose and r.stderr.strip():
             print(r.stderr)
+        with open(cmd[-1] + ".cmd", "w") as fh:
+            fh.write(" ".join(cmd))
         return src
 
     if jobs:
