@@ -54,10 +54,15 @@ __global__ void k_pack_conv(const float* __restrict__ W, float4* __restrict__ Wp
 
 // W [Cout][Cin][ks][ks] -> Wq[ct][tap][cin/16][piece][lane] (16 bytes = 8 bf16): lane holds cout = 32 ct + lane % 32, input channels
 // 16 k16 + 8 (lane / 32) + 0..7 -- the A operand of v_mfma_f32_32x32x16_bf16, one plane per bf16 piece of the weight (bx_split.h).
-__global__ void k_pack_conv_bx(const float* __restrict__ W, u32x4* __restrict__ Wq, int Cout, int Cin, int ks, int CT, int KU) {
+__global__ void k_pack_conv_bx(const float* __restrict__ W, u32x4* __restrict__ Wq, int Cout, int Cin, int ks, int CT, int KU,
+                               long long w_bstride = 0, long long wq_bstride = 0, int transposed = 0) {
+    // blockIdx.y = image for per-image "weights" (the attention's K and V^T, ks = 1): W + y * w_bstride floats, Wq + y * wq_bstride;
+    // transposed: W is stored [Cin][Cout] (W[co][ci] = src[ci * Cout + co])
     const int T = ks * ks;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)CT * T * KU * 64) return;
+    W += (long long)blockIdx.y * w_bstride;
+    Wq += (long long)blockIdx.y * wq_bstride;
     const int lane = (int)(idx & 63);
     long long r = idx >> 6;
     const int ku = (int)(r % KU); r /= KU;
@@ -65,7 +70,8 @@ __global__ void k_pack_conv_bx(const float* __restrict__ W, u32x4* __restrict__ 
     const int ct = (int)(r / T);
     const int co = ct * 32 + (lane & 31), ci0 = ku * 16 + 8 * (lane >> 5);
     float v[8];
-    for (int i = 0; i < 8; ++i) v[i] = (co < Cout && ci0 + i < Cin) ? W[((long long)co * Cin + ci0 + i) * T + tap] : 0.f;
+    for (int i = 0; i < 8; ++i)
+        v[i] = (co < Cout && ci0 + i < Cin) ? (transposed ? W[(long long)(ci0 + i) * Cout + co] : W[((long long)co * Cin + ci0 + i) * T + tap]) : 0.f;
     unsigned h[4], m[4], l[4];
     for (int i = 0; i < 4; ++i) bx_split2(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
     u32x4* o = Wq + (idx >> 6) * 192 + lane;
@@ -82,6 +88,7 @@ struct ConvArgs {
     const float* in;     // NHWC [B][Hs][Ws][Cin]  (Hs,Ws = stored size; the conv sees 2x that when up=1)
     const float4* wp;
     const u32x4* wq;     // k_conv_bx: the weights as bf16 pieces (k_pack_conv_bx)
+    long long wq_bstride;  // > 0: per-image weights (attention), image b uses wq + b * wq_bstride
     const float* bias;   // [CT*32]
     const float* res;    // nullable NHWC [B][Ho][Wo][Cout_s]
     float* out;          // NHWC [B][Ho][Wo][Cout_s]
@@ -388,7 +395,7 @@ __global__ __launch_bounds__(COT * 64) void k_conv_bx(ConvArgs a) {
         }
 #define WMAR_CONVBX_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
     // step it of round r: tap = it / 2, channels 32 r + 16 (it % 2) .. + 15
-    const u32x4* wtile = a.wq + (long long)(active ? ct : 0) * T * KU * 192 + lane;
+    const u32x4* wtile = a.wq + (long long)b * a.wq_bstride + (long long)(active ? ct : 0) * T * KU * 192 + lane;
     u32x4 wr[WR][3], xr[XR][6];
 #define WMAR_CONVBX_LOADW(SLOT, R, IT)                                                                          \
     { const u32x4* wp_ = wtile + ((long long)((IT) >> 1) * KU + 2 * (R) + ((IT) & 1)) * 192;                       \
@@ -600,6 +607,22 @@ __global__ __launch_bounds__(256) void k_attn_pv(const float* __restrict__ sc, c
     }
 }
 
+// softmax over the rows of sc [rows][N] after scaling, in place: one wave per row (the MFMA attention path below)
+__global__ __launch_bounds__(256) void k_attn_softmax(float* __restrict__ sc, long long rows, int N, float scale) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float* p = sc + row * N;
+    float mx = -INFINITY;
+    for (int j = lane; j < N; j += 64) { const float s = p[j] * scale; p[j] = s; mx = fmaxf(mx, s); }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int j = lane; j < N; j += 64) { const float e = __expf(p[j] - mx); p[j] = e; sum += e; }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < N; j += 64) p[j] *= inv;
+}
+
 // ------------------------------------------------------------------------ quantizer
 __global__ void k_codebook_gather(const long long* __restrict__ codes, const float* __restrict__ emb,
                                   float* __restrict__ z, long long npix, int E, int n_embed) {
@@ -769,6 +792,8 @@ struct wmar_vq {
     float* buf[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t buf_elems = 0;
     float *aq = nullptr, *ak = nullptr, *av = nullptr, *ao = nullptr, *asc = nullptr;
+    u32x4 *attk = nullptr, *attv = nullptr;   // per-image K and V^T as bf16-piece conv weights (MFMA attention)
+    float* zbias = nullptr;                    // zeros, max(tokens, channels) long
     double* gn_partial = nullptr;
     double* gn_tiles = nullptr; long long gn_tiles_cap = 0;   // per-tile GroupNorm partial sums written by conv epilogues
     float* znorm = nullptr;
@@ -907,13 +932,13 @@ struct GnRef {
 };
 
 int run_conv(const ConvW& c, const float* in, float* out, const float* res, int B, int Hs, int Ws, int stride, int up,
-             hipStream_t st, const GnRef* gn = nullptr) {
+             hipStream_t st, const GnRef* gn = nullptr, long long wq_bstride = 0) {
     ConvArgs a{};
     if (gn) {
         WMAR_REQUIRE(gn->C == c.cin_s && !up, "fused GroupNorm: channel count %d != conv input %d", gn->C, c.cin_s);
         a.gn_mr = gn->mr; a.gn_g = gn->g; a.gn_b = gn->b; a.gn_cpg = gn->C / 32; a.gn_swish = gn->swish;
     }
-    a.in = in; a.wp = c.wp; a.wq = c.wq; a.bias = c.bias; a.res = res; a.out = out;
+    a.in = in; a.wp = c.wp; a.wq = c.wq; a.wq_bstride = wq_bstride; a.bias = c.bias; a.res = res; a.out = out;
     a.Hs = Hs; a.Ws = Ws; a.Cin = c.cin_s;
     const int Hc = up ? 2 * Hs : Hs, Wc = up ? 2 * Ws : Ws;
     a.Ho = stride == 2 ? Hc / 2 : Hc; a.Wo = stride == 2 ? Wc / 2 : Wc;
@@ -926,7 +951,7 @@ int run_conv(const ConvW& c, const float* in, float* out, const float* res, int 
     a.dbuf = (c.cin_s % CONV_CCH == 0 && PW * PW * 8 <= 4 * COT * 64) ? 1 : 0;
     // statistics of the output for the GroupNorm that (usually) follows: groups of 4 / 8 / 16 channels inside one 32-channel tile
     const int cpg_out = c.cout / 32;
-    const bool stats = g_trk.part && c.cout == c.cout_s && c.cout % 32 == 0 && (cpg_out == 4 || cpg_out == 8 || cpg_out == 16) &&
+    const bool stats = wq_bstride == 0 && g_trk.part && c.cout == c.cout_s && c.cout % 32 == 0 && (cpg_out == 4 || cpg_out == 8 || cpg_out == 16) &&
                        (long long)B * a.tiles_x * a.tiles_y * 64 <= g_trk.cap;
     if (stats) { a.st_part = g_trk.part; a.st_cpg = cpg_out; g_trk.src = out; g_trk.tiles = a.tiles_x * a.tiles_y; g_trk.C = c.cout; }
     else if (g_trk.src == out) g_trk.src = nullptr;      // the tensor the buffer described is being overwritten
@@ -1015,9 +1040,28 @@ int run_attn(wmar_vq* v, const AttnW& w, Bufs& bf, int B, int H, int W, hipStrea
     if ((rc = run_conv(w.k, X, v->ak, nullptr, B, H, W, 1, 0, st, &gn))) return rc;
     if ((rc = run_conv(w.v, X, v->av, nullptr, B, H, W, 1, 0, st, &gn))) return rc;
     const float scale = 1.0f / sqrtf((float)C);   // int(c)**(-0.5)
-    hipLaunchKernelGGL(k_attn_scores, dim3(N, B), dim3(256), (size_t)C * 4, st, v->aq, v->ak, v->asc, N, C, scale);
-    hipLaunchKernelGGL(k_attn_pv, dim3(N, B), dim3(256), (size_t)N * 4, st, v->asc, v->av, v->ao, N, C);
-    if ((rc = launch_status("k_attn"))) return rc;
+    if (v->attk && N % 32 == 0 && C % 32 == 0 && H % 8 == 0 && W % 8 == 0 && N >= 64 && C >= 64 && !conv_no_bx()) {
+        // Both products as 1x1 convolutions with PER-IMAGE weights on the bf16 matrix pipe (k_conv_bx): scores = conv(q; weights K_b),
+        // out = conv(softmax(scores); weights V_b^T).  K_b and V_b^T are split into bf16 pieces by the weight packer.
+        ConvW ck{}, cv{};
+        ck.wq = v->attk; ck.bias = v->zbias; ck.cin = ck.cin_s = C; ck.cout = ck.cout_s = N; ck.ks = 1; ck.CT = N / 32; ck.KBc = C / 8;
+        cv.wq = v->attv; cv.bias = v->zbias; cv.cin = cv.cin_s = N; cv.cout = cv.cout_s = C; cv.ks = 1; cv.CT = C / 32; cv.KBc = N / 8;
+        const long long sk = (long long)ck.CT * (C / 16) * 192, sv = (long long)cv.CT * (N / 16) * 192;
+        const long long nk = (long long)ck.CT * (C / 16) * 64, nv = (long long)cv.CT * (N / 16) * 64;
+        hipLaunchKernelGGL(k_pack_conv_bx, dim3((unsigned)((nk + 255) / 256), B), dim3(256), 0, st, (const float*)v->ak, v->attk, N, C, 1, ck.CT,
+                           C / 16, (long long)N * C, sk, 0);
+        hipLaunchKernelGGL(k_pack_conv_bx, dim3((unsigned)((nv + 255) / 256), B), dim3(256), 0, st, (const float*)v->av, v->attv, C, N, 1, cv.CT,
+                           N / 16, (long long)N * C, sv, 1);
+        if ((rc = launch_status("k_pack_conv_bx"))) return rc;
+        if ((rc = run_conv(ck, v->aq, v->asc, nullptr, B, H, W, 1, 0, st, nullptr, sk))) return rc;
+        hipLaunchKernelGGL(k_attn_softmax, dim3((unsigned)(((long long)B * N + 3) / 4)), dim3(256), 0, st, v->asc, (long long)B * N, N, scale);
+        if ((rc = launch_status("k_attn_softmax"))) return rc;
+        if ((rc = run_conv(cv, v->asc, v->ao, nullptr, B, H, W, 1, 0, st, nullptr, sv))) return rc;
+    } else {
+        hipLaunchKernelGGL(k_attn_scores, dim3(N, B), dim3(256), (size_t)C * 4, st, v->aq, v->ak, v->asc, N, C, scale);
+        hipLaunchKernelGGL(k_attn_pv, dim3(N, B), dim3(256), (size_t)N * 4, st, v->asc, v->av, v->ao, N, C);
+        if ((rc = launch_status("k_attn"))) return rc;
+    }
     if ((rc = run_conv(w.proj, v->ao, T, X, B, H, W, 1, 0, st))) return rc;
     bf.advance(2);
     return WMAR_OK;
@@ -1155,6 +1199,13 @@ int wmar_vq_create(const wmar_vq_config* cfg, const char* const* names, const vo
     TRY(v->alloc(&v->av, (size_t)v->Bmax * ntok * cam));
     TRY(v->alloc(&v->ao, (size_t)v->Bmax * ntok * cam));
     TRY(v->alloc(&v->asc, (size_t)v->Bmax * ntok * ntok));
+    if (ntok % 32 == 0 && cam % 32 == 0) {
+        TRY(v->alloc(&v->attk, (size_t)v->Bmax * ntok * cam * 3 / 8));     // 3 pieces x 2 bytes per element, in 16-byte units
+        TRY(v->alloc(&v->attv, (size_t)v->Bmax * ntok * cam * 3 / 8));
+        const size_t nz = ntok > (size_t)cam ? ntok : (size_t)cam;
+        TRY(v->alloc(&v->zbias, nz));
+        if (rc == WMAR_OK && hipMemsetAsync(v->zbias, 0, nz * 4, st) != hipSuccess) { set_error("vq_create: memset failed"); rc = WMAR_EHIP; }
+    }
     TRY(v->alloc(&v->gn_partial, (size_t)GN_MR_DOUBLES + (size_t)v->Bmax * GN_CHUNKS_MAX * 32 * 2));
     v->gn_tiles_cap = (long long)v->Bmax * (cfg->resolution / 8) * (cfg->resolution / 8) * 64;
     TRY(v->alloc(&v->gn_tiles, (size_t)v->gn_tiles_cap));
