@@ -361,8 +361,8 @@ __global__ __launch_bounds__(COT * 64) void k_conv_bx(ConvArgs a) {
     const int prow = j >> 3, pcol = j & 7;
     const float* inb = a.in + (long long)b * a.Hs * a.Ws * a.Cin;
 
-    constexpr int NPT = 4;
     constexpr int nelem = PH * PW * 8;
+    constexpr int NPT = (nelem + COT * 64 - 1) / (COT * 64);     // float4 per thread of a 32-channel patch (4 with 4 waves, 13 with 1)
     long long goff[NPT];
     int loff[NPT];
 #pragma unroll
@@ -955,7 +955,9 @@ int run_conv(const ConvW& c, const float* in, float* out, const float* res, int 
                        (long long)B * a.tiles_x * a.tiles_y * 64 <= g_trk.cap;
     if (stats) { a.st_part = g_trk.part; a.st_cpg = cpg_out; g_trk.src = out; g_trk.tiles = a.tiles_x * a.tiles_y; g_trk.C = c.cout; }
     else if (g_trk.src == out) g_trk.src = nullptr;      // the tensor the buffer described is being overwritten
-    const bool bx = a.dbuf && c.wq && stride == 1 && (c.ks == 3 || c.ks == 1) && !conv_no_bx();
+    // k_conv_bx stages (PW * PW * 8) / threads float4 per thread: up to 13 (one wave per workgroup: the 128 -> 3 output conv)
+    const bool bx = c.wq && c.cin_s % CONV_CCH == 0 && stride == 1 && (c.ks == 3 || c.ks == 1) && !conv_no_bx();
+    if (bx) a.dbuf = 1;
     const size_t lds = bx ? (size_t)2 * PW * PW * CONV_PSTRIDE_BX : (size_t)(a.dbuf ? 2 : 1) * PW * PW * CONV_PSTRIDE * sizeof(float);
     const int cgroups = (c.CT + COT - 1) / COT;
     const unsigned grid = (unsigned)((long long)B * cgroups * a.tiles_x * a.tiles_y);
