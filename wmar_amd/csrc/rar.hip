@@ -304,14 +304,23 @@ struct RarPlan {
         t.kcache = g->kcache + l * lstride; t.vcache = g->vcache + l * lstride; t.y = g->y; t.pos_dev = g->ctr;
         t.D = D; t.H = g->H; t.Tmax = g->T; t.MT = MT; t.scale = 1.0f / sqrtf((float)g->hd);
         const dim3 grid((unsigned)(M * g->H));
+        int nwa = 1;      // measured at 128 rows, head_dim 80, 256 positions: 4.58 / 4.75 / 4.83 ms per step with 1 / 2 / 4 waves per (sequence, head)
+#ifdef WMAR_DEV_KNOBS
+        { const char* e = getenv("WMAR_RAR_ATT_NW"); if (e) nwa = atoi(e); }
+#endif
+#define WMAR_RAR_ATT(HDV)                                                                                   \
+        if (nwa == 1) hipLaunchKernelGGL((k_attn_decode<HDV, 1>), grid, dim3(64), 0, st, t);                \
+        else if (nwa == 4) hipLaunchKernelGGL((k_attn_decode<HDV, 4>), grid, dim3(256), 0, st, t);          \
+        else hipLaunchKernelGGL((k_attn_decode<HDV, 2>), grid, dim3(128), 0, st, t);
         switch (g->hd) {
-            case 32: hipLaunchKernelGGL((k_attn_decode<32, 2>), grid, dim3(128), 0, st, t); break;
-            case 48: hipLaunchKernelGGL((k_attn_decode<48, 2>), grid, dim3(128), 0, st, t); break;
-            case 64: hipLaunchKernelGGL((k_attn_decode<64, 2>), grid, dim3(128), 0, st, t); break;
-            case 80: hipLaunchKernelGGL((k_attn_decode<80, 2>), grid, dim3(128), 0, st, t); break;
-            case 88: hipLaunchKernelGGL((k_attn_decode<88, 2>), grid, dim3(128), 0, st, t); break;
-            default: hipLaunchKernelGGL((k_attn_decode<128, 2>), grid, dim3(128), 0, st, t); break;
+            case 32: WMAR_RAR_ATT(32) break;
+            case 48: WMAR_RAR_ATT(48) break;
+            case 64: WMAR_RAR_ATT(64) break;
+            case 80: WMAR_RAR_ATT(80) break;
+            case 88: WMAR_RAR_ATT(88) break;
+            default: WMAR_RAR_ATT(128) break;
         }
+#undef WMAR_RAR_ATT
         if ((rc = launch_status("k_attn_decode"))) return rc;
         GemmArgs p = base();
         p.Wp = w.wproj; p.Xp = g->y; p.KB = KBD; p.NT = D / 32; p.out_packed = g->slabs; p.slab_stride = act;
