@@ -220,16 +220,32 @@ __global__ __launch_bounds__(256, BX_OCC) void k_bx6(BxArgs a) {
 #if BX_LAST
     // the last workgroup of a column group to arrive sums the S slabs in slab order (the same result whoever is last)
     __shared__ unsigned last_flag;
+#if BX_LAST == 2
+    // slabs and counters live in UNCACHED (MTYPE_UC) device memory: stores are acknowledged by the memory side, so waiting for
+    // this wave's stores + a relaxed device-scope atomic is the release; the acquire is an L1/L2 invalidate of non-local lines
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
     __threadfence();
+#endif
     __syncthreads();
     if (threadIdx.x == 0) {
+#if BX_LAST == 2
+        const unsigned old = __hip_atomic_fetch_add(a.cnt + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = old == (unsigned)a.S - 1;
+        if (last_flag) __hip_atomic_store(a.cnt + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
         const unsigned old = atomicAdd(a.cnt + grp, 1u);
         last_flag = old == (unsigned)a.S - 1;
         if (last_flag) a.cnt[grp] = 0;
+#endif
     }
     __syncthreads();
     if (last_flag) {
+#if BX_LAST == 2
+        asm volatile("buffer_inv sc1" ::: "memory");
+#else
         __threadfence();
+#endif
 #pragma unroll
         for (int r = 0; r < NT * 2; ++r) {
             const int row = r * 4 + w, t = row >> 3, i = (row >> 2) & 1, g = row & 3;
@@ -264,7 +280,11 @@ static void run(const char* name, int N, int K, int S, hipStream_t st) {
     (void)hipMalloc(&X, hX.size() * 4); (void)hipMemcpy(X, hX.data(), hX.size() * 4, hipMemcpyHostToDevice);
     (void)hipMalloc(&Xq, (size_t)K / 16 * 6 * 64 * 16);
     const size_t slab = (size_t)N * 64 / 4;
+#if BX_LAST == 2
+    if (hipExtMallocWithFlags((void**)&out, slab * S * 16, hipDeviceMallocUncached) != hipSuccess) { printf("uncached alloc failed\n"); return; }
+#else
     (void)hipMalloc(&out, slab * S * 16);
+#endif
     hipLaunchKernelGGL(k_pack_x, dim3((K / 16 * 128 + 255) / 256), dim3(256), 0, st, X, Xq, K);
     std::vector<float4*> Wq(NL);
     for (int l = 0; l < NL; ++l) {
@@ -274,7 +294,13 @@ static void run(const char* name, int N, int K, int S, hipStream_t st) {
     }
     const int grid = N / 32 / NT * S;
     unsigned long long* tr; (void)hipMalloc(&tr, 1024 * 32 * 8); (void)hipMemset(tr, 0, 1024 * 32 * 8);
-    unsigned* cnt; (void)hipMalloc(&cnt, 4096); (void)hipMemset(cnt, 0, 4096);
+    unsigned* cnt;
+#if BX_LAST == 2
+    (void)hipExtMallocWithFlags((void**)&cnt, 4096, hipDeviceMallocUncached);
+#else
+    (void)hipMalloc(&cnt, 4096);
+#endif
+    (void)hipMemset(cnt, 0, 4096);
     float4* fin; (void)hipMalloc(&fin, slab * 16);
     BxArgs a{}; a.Xq = Xq; a.out = out; a.KU = K / 16; a.S = S; a.slab_stride = slab; a.trace = tr; a.cnt = cnt; a.fin = fin;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
