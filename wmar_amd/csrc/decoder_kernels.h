@@ -225,6 +225,7 @@ struct GemmArgs {
     const double* stats; int n_chunks; int K;
     // epilogues
     float4* out_packed; long long slab_stride;          // EPI_PACKED (slab s) / EPI_GELU
+    u32x4* out_planes;                                  // EPI_GELU, nullable: the activation as bf16 pieces instead (a k_bx GEMM follows)
     float* qbuf; float* kcache; float* vcache;          // EPI_QKV
     const int* pos_dev; int D, H, hd, Tmax;
     float* logits; int V;                               // EPI_LOGITS
@@ -458,8 +459,12 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
                 for (int j = 0; j < 4; ++j) o[j] = gelu_erf(o[j]);
             }
             // output column n is input feature k' = n of the next GEMM: kb' = n/8
-            float4* dst = a.out_packed + (long long)s * a.slab_stride + ((long long)(nt * 4 + g) * a.MT + mt) * 64 + lane;
-            *dst = make_float4(o[0], o[1], o[2], o[3]);
+            if (EPI == EPI_GELU && a.out_planes) {
+                bx_store_planes4(a.out_planes, a.MT, nt * 4 + g, lane >> 5, mt, lane & 31, make_float4(o[0], o[1], o[2], o[3]));
+            } else {
+                float4* dst = a.out_packed + (long long)s * a.slab_stride + ((long long)(nt * 4 + g) * a.MT + mt) * 64 + lane;
+                *dst = make_float4(o[0], o[1], o[2], o[3]);
+            }
         } else if (EPI == EPI_QKV) {
             if (m < a.B) {
                 const int which = n / a.D, c = n % a.D;
@@ -1213,8 +1218,8 @@ static int launch_qkvx_bx(const QkvxArgs& q, int S_in, hipStream_t st) {
 // issue, MFMAs included (scripts/stream_profile.hip, scripts/bx6_bench.hip).
 struct BxArgs {
     const float4* Wq;          // k_pack_bx layout
-    const u32x4* Xq;           // activation planes [K/16][2][3][64] (64 rows)
-    float4* out;               // slab s at out + s * slab_stride, packed [N/8][2][64]
+    const u32x4* Xq;           // activation planes [K/16][MTW][3][64]
+    float4* out;               // slab s at out + s * slab_stride, packed [N/8][MTW][64]
     long long slab_stride;     // float4 units
     int KU;                    // K / 16
     int S;                     // K slices: KU == 4 * PER * S
@@ -1222,32 +1227,35 @@ struct BxArgs {
 
 #define WMAR_BX_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
 
-template <int NT, int PER>
+template <int NT, int PER, int MTW = 2>
 __global__ __launch_bounds__(256) void k_bx(BxArgs a) {
-    __shared__ __attribute__((aligned(16))) float4 red[4][NT * 8][64];
+    // MTW row tiles of 32 (2: 64 rows, 4: 128 rows -- RAR under guidance); planes [K/16][MTW][3][64], slabs packed [N/8][MTW][64]
+    constexpr int XR = 3 * MTW;             // 16-byte operand loads of a step
+    constexpr int ROWS = NT * 4 * MTW;      // float4 rows (tile, row tile, register group) of the workgroup's output
+    __shared__ __attribute__((aligned(16))) float4 red[4][ROWS][64];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // slice = id % S: with S a multiple of 4 every XCD (id % 8) works on one or two K slices and keeps only those in its L2
     const int grp = (int)blockIdx.x / a.S, ks = (int)blockIdx.x % a.S;
     const int u0 = (ks * 4 + w) * PER;
-    f32x16 acc[NT][2];
+    f32x16 acc[NT][MTW];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MTW; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.f;
     const float4* wp = a.Wq + ((long long)grp * NT * a.KU + u0) * 128 + lane;
     const long long wt = (long long)a.KU * 128;     // next column tile
-    const u32x4* xp = a.Xq + (long long)u0 * 6 * 64 + lane;
+    const u32x4* xp = a.Xq + (long long)u0 * XR * 64 + lane;
     float4 wr[NT][2];
-    u32x4 xr[6];
+    u32x4 xr[XR];
 #define WMAR_BX_LOADW(U)                                                                           \
     { _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                             \
         wr[t][0] = ld_nt(wp + t * wt + (long long)(U) * 128);                                      \
         wr[t][1] = ld_nt(wp + t * wt + (long long)(U) * 128 + 64); } }
 #define WMAR_BX_LOADX(U)                                                                           \
-    { _Pragma("unroll") for (int q = 0; q < 6; ++q) xr[q] = xp[(long long)(U) * 384 + q * 64]; }
+    { _Pragma("unroll") for (int q = 0; q < XR; ++q) xr[q] = xp[(long long)(U) * (XR * 64) + q * 64]; }
     WMAR_BX_LOADW(0);
     WMAR_BX_LOADX(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -1265,25 +1273,18 @@ __global__ __launch_bounds__(256) void k_bx(BxArgs a) {
             for (int t = 0; t < NT; ++t) bx_split8(wr[t][0], wr[t][1], ph[n][t], pm[n][t], pl[n][t]);
             if (j + 2 < PER) WMAR_BX_LOADW(j + 2);
         }
-        bf16x8 x[6];
+        bf16x8 x[XR];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) x[q] = __builtin_bit_cast(bf16x8, xr[q]);
+        for (int q = 0; q < XR; ++q) x[q] = __builtin_bit_cast(bf16x8, xr[q]);
         // x[3 mt + piece]; the small products first
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { WMAR_BX_MFMA(pl[c][t], x[0], acc[t][0]); WMAR_BX_MFMA(pl[c][t], x[3], acc[t][1]); }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { WMAR_BX_MFMA(ph[c][t], x[2], acc[t][0]); WMAR_BX_MFMA(ph[c][t], x[5], acc[t][1]); }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { WMAR_BX_MFMA(pm[c][t], x[1], acc[t][0]); WMAR_BX_MFMA(pm[c][t], x[4], acc[t][1]); }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { WMAR_BX_MFMA(pm[c][t], x[0], acc[t][0]); WMAR_BX_MFMA(pm[c][t], x[3], acc[t][1]); }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { WMAR_BX_MFMA(ph[c][t], x[1], acc[t][0]); WMAR_BX_MFMA(ph[c][t], x[4], acc[t][1]); }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { WMAR_BX_MFMA(ph[c][t], x[0], acc[t][0]); WMAR_BX_MFMA(ph[c][t], x[3], acc[t][1]); }
+#define WMAR_BX_ROUND(WP, XP)                                                                      \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                             \
+            _Pragma("unroll") for (int i = 0; i < MTW; ++i) WMAR_BX_MFMA(WP[c][t], x[3 * i + XP], acc[t][i]);
+        WMAR_BX_ROUND(pl, 0) WMAR_BX_ROUND(ph, 2) WMAR_BX_ROUND(pm, 1) WMAR_BX_ROUND(pm, 0) WMAR_BX_ROUND(ph, 1) WMAR_BX_ROUND(ph, 0)
+#undef WMAR_BX_ROUND
         if (j + 1 < PER) WMAR_BX_LOADX(j + 1);
 #pragma unroll
-        for (int i = 0; i < 12 * NT; ++i) {
+        for (int i = 0; i < 6 * MTW * NT; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
             if (i % 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -1295,29 +1296,29 @@ __global__ __launch_bounds__(256) void k_bx(BxArgs a) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MTW; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                red[w][(t * 2 + i) * 4 + g][lane] = make_float4(acc[t][i][4 * g], acc[t][i][4 * g + 1], acc[t][i][4 * g + 2], acc[t][i][4 * g + 3]);
+                red[w][(t * MTW + i) * 4 + g][lane] = make_float4(acc[t][i][4 * g], acc[t][i][4 * g + 1], acc[t][i][4 * g + 2], acc[t][i][4 * g + 3]);
     __syncthreads();
-    // wave w sums rows w, w + 4, ... of the NT * 8 (tile, row tile, register group) rows over the four K quarters, in fixed order
+    // wave w sums rows w, w + 4, ... of the (tile, row tile, register group) rows over the four K quarters, in fixed order
     float4* out = a.out + (long long)ks * a.slab_stride;
 #pragma unroll
-    for (int r = 0; r < NT * 2; ++r) {
-        const int row = r * 4 + w, t = row >> 3, i = (row >> 2) & 1, g = row & 3;
+    for (int r = 0; r < ROWS / 4; ++r) {
+        const int row = r * 4 + w, t = row / (4 * MTW), i = (row >> 2) % MTW, g = row & 3;
         float4 v = red[0][row][lane];
 #pragma unroll
         for (int o = 1; o < 4; ++o) { const float4 q = red[o][row][lane]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-        out[((long long)((grp * NT + t) * 4 + g) * 2 + i) * 64 + lane] = v;
+        out[((long long)((grp * NT + t) * 4 + g) * MTW + i) * 64 + lane] = v;
     }
 }
 
 constexpr int BX_PER = 6;              // 16-k steps per wave: K slice = 4 waves x 6 x 16 = 384
 constexpr int BX_KSLICE = 4 * BX_PER * 16;
-// N must be a multiple of 32 * NT, K of 384; 64 rows (MT = 2)
-template <int NT>
+// N must be a multiple of 32 * NT, K = S * 64 * PER; 32 * MTW rows
+template <int NT, int PER = BX_PER, int MTW = 2>
 static int launch_bx(const BxArgs& a, int N, hipStream_t st) {
-    hipLaunchKernelGGL((k_bx<NT, BX_PER>), dim3((unsigned)(N / (32 * NT) * a.S)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_bx<NT, PER, MTW>), dim3((unsigned)(N / (32 * NT) * a.S)), dim3(256), 0, st, a);
     return launch_status("k_bx");
 }
 

@@ -104,6 +104,7 @@ struct ModArgs {
     const float* shift_u; const float* scale_u;   // nullable: rows >= split share row *pos_dev of the [T][mod_stride] table
     const int* pos_dev; int split;
     int KB, MT, n_chunks, K;
+    u32x4* hq;      // nullable: write the modulated rows as bf16 pieces (a k_bx GEMM follows) instead of h
 };
 
 static __global__ __launch_bounds__(256) void k_modulate(ModArgs a) {
@@ -154,8 +155,10 @@ static __global__ __launch_bounds__(256) void k_modulate(ModArgs a) {
         if (a.gamma) {
             r[0] = r[0] * g4[i].x + b4[i].x; r[1] = r[1] * g4[i].y + b4[i].y; r[2] = r[2] * g4[i].z + b4[i].z; r[3] = r[3] * g4[i].w + b4[i].w;
         }
-        a.h[((long long)kb * a.MT + mt) * 64 + lane] = make_float4(r[0] * (1.0f + sc[i].x) + sh[i].x, r[1] * (1.0f + sc[i].y) + sh[i].y,
-                                                                r[2] * (1.0f + sc[i].z) + sh[i].z, r[3] * (1.0f + sc[i].w) + sh[i].w);
+        const float4 hv = make_float4(r[0] * (1.0f + sc[i].x) + sh[i].x, r[1] * (1.0f + sc[i].y) + sh[i].y,
+                                      r[2] * (1.0f + sc[i].z) + sh[i].z, r[3] * (1.0f + sc[i].w) + sh[i].w);
+        if (a.hq) bx_store_planes4(a.hq, a.MT, kb, half, mt, lane & 31, hv);
+        else a.h[((long long)kb * a.MT + mt) * 64 + lane] = hv;
     }
 }
 
@@ -182,8 +185,35 @@ static __global__ void k_set3(int* p, int a, int b, int c) { p[0] = a; p[1] = b;
 
 using namespace wmar;
 
+// split of a k_bx GEMM: K = 64 S PER with S <= MAX_SLABS slabs, as many of the `tiles` x S workgroups as fit one per CU
+struct BxShape { int S = 0, PER = 0; };
+static BxShape bx_shape(int tiles, int KU) {
+    BxShape best{};
+    const int pers[] = {4, 5, 8, 10, 16, 20};
+    for (int per : pers) {
+        if (KU % (4 * per)) continue;
+        const int S = KU / (4 * per);
+        if (S < 1 || S > MAX_SLABS || tiles * S > 256) continue;
+        if (tiles * S > tiles * best.S) best = BxShape{S, per};
+    }
+    return best;
+}
+template <int NT>
+static int launch_bx4(const BxArgs& a, int N, int PER, hipStream_t st) {
+    switch (PER) {
+        case 4: return launch_bx<NT, 4, 4>(a, N, st);
+        case 5: return launch_bx<NT, 5, 4>(a, N, st);
+        case 8: return launch_bx<NT, 8, 4>(a, N, st);
+        case 10: return launch_bx<NT, 10, 4>(a, N, st);
+        case 16: return launch_bx<NT, 16, 4>(a, N, st);
+        case 20: return launch_bx<NT, 20, 4>(a, N, st);
+        default: set_error("k_bx: %d steps per wave unsupported", PER); return WMAR_EINVAL;
+    }
+}
+
 struct RarLayer {
     float4 *wqkv, *wproj, *wfc1, *wfc2;
+    float4 *wqkv_bx = nullptr, *wproj_bx = nullptr, *wfc2_bx = nullptr;   // k_pack_bx order (128-row steps on the bf16 matrix pipe)
     float *bqkv, *bproj, *bfc1, *bfc2, *n1w, *n1b, *n2w, *n2b, *qnw, *qnb, *knw, *knb;
 };
 
@@ -198,6 +228,10 @@ struct wmar_rar {
     float *bada = nullptr, *bhead = nullptr;
     // workspaces
     float4 *x = nullptr, *h = nullptr, *y = nullptr, *hbuf = nullptr, *sc = nullptr, *slabs = nullptr, *qkv_slabs = nullptr;
+    // 128-row steps (guidance at batch 33..64): QKV, proj and FC2 as k_bx on bf16 pieces; (K slices, 16-k steps per wave) per GEMM
+    u32x4 *xq = nullptr, *yq = nullptr, *hq = nullptr;
+    BxShape bx_qkv, bx_proj, bx_fc2;
+    bool bx_ok = false, no_bx = false;
     float* mod = nullptr;
     float* mod_u = nullptr;   // [T][Ntot] modulations of the unconditional row at every position (built on first guided generate)
     bool mod_u_ready = false;
@@ -239,6 +273,7 @@ struct RarPlan {
     const long long* tok;   // explicit tokens (forward_position) or null
     bool shared_u;          // rows [Bhalf, M) all carry the "none" condition: their adaLN modulation comes from g->mod_u
     int MTc;                // row tiles of the adaLN GEMM
+    bool bx = false;        // 128 rows: QKV / proj / FC2 on the bf16 matrix pipe
 
     RarPlan(wmar_rar* g_, int M_, int Bhalf_, const long long* tok_, hipStream_t st_, bool shared_u_ = false)
         : g(g_), M(M_), Bhalf(Bhalf_), st(st_), tok(tok_), shared_u(shared_u_) {
@@ -248,6 +283,8 @@ struct RarPlan {
         const int tiles = MT % 2 == 0 ? (D / 32) * (MT / 2) : (D / 32) * MT;
         S_proj = pick_split(tiles, KBD, 4);
         S_fc2 = pick_split(tiles, KBF, 4);
+        bx = MT == 4 && g->bx_ok && !g->no_bx;
+        if (bx) { S_proj = g->bx_proj.S; S_fc2 = g->bx_fc2.S; }
     }
     GemmArgs base() const {
         GemmArgs a{};
@@ -271,8 +308,9 @@ struct RarPlan {
         if (shared_u) { a.MT = MTc; a.B = Bhalf; }
         return gemm_dispatch<EPI_LOGITS, false>(a, false, st);
     }
-    int modulate(const float* gamma, const float* beta, long long off_shift, long long off_scale) {
+    int modulate(const float* gamma, const float* beta, long long off_shift, long long off_scale, u32x4* planes = nullptr) {
         ModArgs m{};
+        m.hq = planes;
         m.x = g->x; m.h = g->h; m.stats = g->stats; m.gamma = gamma; m.beta = beta;
         m.shift = g->mod + off_shift; m.scale = g->mod + off_scale; m.mod_stride = g->Ntot;
         if (shared_u) { m.shift_u = g->mod_u + off_shift; m.scale_u = g->mod_u + off_scale; m.split = Bhalf; }
@@ -293,15 +331,24 @@ struct RarPlan {
         const RarLayer& w = g->layers[l];
         const long long o = (long long)l * 6 * D;   // chunk(6): shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
         int rc, S = 1;
-        if ((rc = modulate(w.n1w, w.n1b, o, o + D))) return rc;
-        GemmArgs a = base();
-        a.Wp = w.wqkv; a.Xp = g->h; a.KB = KBD; a.NT = 3 * D / 32; a.out_packed = g->qkv_slabs; a.slab_stride = 3 * act;
-        if ((rc = gemm_split(a, &S, st, 1))) return rc;
+        int S_qkv = 1;
+        if (bx) {
+            if ((rc = modulate(w.n1w, w.n1b, o, o + D, g->xq))) return rc;
+            BxArgs x{};
+            x.Wq = w.wqkv_bx; x.Xq = g->xq; x.out = g->qkv_slabs; x.slab_stride = 3 * act; x.KU = D / 16; x.S = g->bx_qkv.S;
+            if ((rc = launch_bx4<2>(x, 3 * D, g->bx_qkv.PER, st))) return rc;     // 64-column groups: half the activation reads per column
+            S_qkv = g->bx_qkv.S;
+        } else {
+            if ((rc = modulate(w.n1w, w.n1b, o, o + D))) return rc;
+            GemmArgs a = base();
+            a.Wp = w.wqkv; a.Xp = g->h; a.KB = KBD; a.NT = 3 * D / 32; a.out_packed = g->qkv_slabs; a.slab_stride = 3 * act;
+            if ((rc = gemm_split(a, &S, st, 1))) return rc;
+        }
         AttnArgs t{};
         const long long lstride = (long long)g->Mmax * g->H * g->T * g->hd;
-        t.qkv_slabs = g->qkv_slabs; t.slab_stride = 3 * act; t.S = 1; t.stats = g->stats; t.n_chunks = nch; t.K = D; t.invK = 1.0 / (double)D;
+        t.qkv_slabs = g->qkv_slabs; t.slab_stride = 3 * act; t.S = S_qkv; t.stats = g->stats; t.n_chunks = nch; t.K = D; t.invK = 1.0 / (double)D;
         t.bias = w.bqkv; t.mode = 1; t.qn_w = w.qnw; t.qn_b = w.qnb; t.kn_w = w.knw; t.kn_b = w.knb;
-        t.kcache = g->kcache + l * lstride; t.vcache = g->vcache + l * lstride; t.y = g->y; t.pos_dev = g->ctr;
+        t.kcache = g->kcache + l * lstride; t.vcache = g->vcache + l * lstride; t.y = g->y; t.yq = bx ? g->yq : nullptr; t.pos_dev = g->ctr;
         t.D = D; t.H = g->H; t.Tmax = g->T; t.MT = MT; t.scale = 1.0f / sqrtf((float)g->hd);
         const dim3 grid((unsigned)(M * g->H));
         int nwa = 1;      // measured at 128 rows, head_dim 80, 256 positions: 4.58 / 4.75 / 4.83 ms per step with 1 / 2 / 4 waves per (sequence, head)
@@ -322,17 +369,30 @@ struct RarPlan {
         }
 #undef WMAR_RAR_ATT
         if ((rc = launch_status("k_attn_decode"))) return rc;
-        GemmArgs p = base();
-        p.Wp = w.wproj; p.Xp = g->y; p.KB = KBD; p.NT = D / 32; p.out_packed = g->slabs; p.slab_stride = act;
-        if ((rc = gemm_split(p, &S, st, S_proj))) return rc;
+        if (bx) {
+            BxArgs x{};
+            x.Wq = w.wproj_bx; x.Xq = g->yq; x.out = g->slabs; x.slab_stride = act; x.KU = D / 16; x.S = g->bx_proj.S;
+            if ((rc = launch_bx4<1>(x, D, g->bx_proj.PER, st))) return rc;
+        } else {
+            GemmArgs p = base();
+            p.Wp = w.wproj; p.Xp = g->y; p.KB = KBD; p.NT = D / 32; p.out_packed = g->slabs; p.slab_stride = act;
+            if ((rc = gemm_split(p, &S, st, S_proj))) return rc;
+        }
         if ((rc = resid(w.bproj, S_proj, o + 2 * D))) return rc;
         if ((rc = modulate(w.n2w, w.n2b, o + 3 * D, o + 4 * D))) return rc;
         GemmArgs f = base();
         f.Wp = w.wfc1; f.Xp = g->h; f.bias = w.bfc1; f.KB = KBD; f.NT = g->F / 32; f.out_packed = g->hbuf;
+        f.out_planes = bx ? g->hq : nullptr;
         if ((rc = gemm_dispatch<EPI_GELU, false>(f, false, st))) return rc;
-        GemmArgs q = base();
-        q.Wp = w.wfc2; q.Xp = g->hbuf; q.KB = KBF; q.NT = D / 32; q.out_packed = g->slabs; q.slab_stride = act;
-        if ((rc = gemm_split(q, &S, st, S_fc2))) return rc;
+        if (bx) {
+            BxArgs x{};
+            x.Wq = w.wfc2_bx; x.Xq = g->hq; x.out = g->slabs; x.slab_stride = act; x.KU = g->F / 16; x.S = g->bx_fc2.S;
+            if ((rc = launch_bx4<2>(x, D, g->bx_fc2.PER, st))) return rc;
+        } else {
+            GemmArgs q = base();
+            q.Wp = w.wfc2; q.Xp = g->hbuf; q.KB = KBF; q.NT = D / 32; q.out_packed = g->slabs; q.slab_stride = act;
+            if ((rc = gemm_split(q, &S, st, S_fc2))) return rc;
+        }
         return resid(w.bfc2, S_fc2, o + 5 * D);
     }
     int head(float* logits_out) {
@@ -398,6 +458,13 @@ int wmar_rar_create(const wmar_rar_config* cfg, const char* const* names, const 
         TRY(g->alloc(&g->wada, (size_t)g->Ntot * D / 4));
         TRY(g->alloc(&g->bada, (size_t)g->Ntot));
     }
+    if (g->MTmax >= 4 && D % 32 == 0 && F % 32 == 0) {
+        g->bx_qkv = bx_shape(3 * D / 64, D / 16); g->bx_proj = bx_shape(D / 32, D / 16); g->bx_fc2 = bx_shape(D / 64, F / 16);
+        g->bx_ok = D % 64 == 0 && g->bx_qkv.S > 0 && g->bx_qkv.S <= QKV_SLABS_MAX && g->bx_proj.S > 0 && g->bx_fc2.S > 0;
+    }
+#ifdef WMAR_DEV_KNOBS
+    g->no_bx = getenv("WMAR_NO_BX") != nullptr;
+#endif
     g->layers.resize(L);
     for (int l = 0; l < L && rc == WMAR_OK; ++l) {
         const std::string p = "blocks." + std::to_string(l) + ".";
@@ -418,6 +485,16 @@ int wmar_rar_create(const wmar_rar_config* cfg, const char* const* names, const 
         TRY(copy_vec(g, &w.bfc1, f1b, (size_t)F, st));
         TRY(g->alloc(&w.wfc2, (size_t)F * D / 4)); TRY(pack(f2w, w.wfc2, D, F, 0, st));
         TRY(copy_vec(g, &w.bfc2, f2b, (size_t)D, st));
+        if (g->bx_ok) {
+            auto pack_bx = [&](const float* W, float4* Wq, int N, int K) -> int {
+                const long long total = (long long)(N / 32) * (K / 16) * 128;
+                hipLaunchKernelGGL(k_pack_bx, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, (const float*)nullptr, Wq, N, K, 0);
+                return launch_status("k_pack_bx");
+            };
+            TRY(g->alloc(&w.wqkv_bx, (size_t)3 * D * D / 4)); TRY(pack_bx(qw, w.wqkv_bx, 3 * D, D));
+            TRY(g->alloc(&w.wproj_bx, (size_t)D * D / 4)); TRY(pack_bx(pw, w.wproj_bx, D, D));
+            TRY(g->alloc(&w.wfc2_bx, (size_t)F * D / 4)); TRY(pack_bx(f2w, w.wfc2_bx, D, F));
+        }
         TRY(copy_vec(g, &w.n1w, n1w, (size_t)D, st)); TRY(copy_vec(g, &w.n1b, n1b, (size_t)D, st));
         TRY(copy_vec(g, &w.n2w, n2w, (size_t)D, st)); TRY(copy_vec(g, &w.n2b, n2b, (size_t)D, st));
         TRY(copy_vec(g, &w.qnw, qnw, (size_t)hd, st)); TRY(copy_vec(g, &w.qnb, qnb, (size_t)hd, st));
@@ -441,7 +518,13 @@ int wmar_rar_create(const wmar_rar_config* cfg, const char* const* names, const 
     TRY(g->alloc(&g->sc, Mpad * D / 4));
     TRY(g->alloc(&g->hbuf, Mpad * F / 4));
     TRY(g->alloc(&g->slabs, (size_t)MAX_SLABS * Mpad * D / 4));
-    TRY(g->alloc(&g->qkv_slabs, Mpad * 3 * D / 4));
+    TRY(g->alloc(&g->qkv_slabs, (size_t)(g->bx_ok ? g->bx_qkv.S : 1) * Mpad * 3 * D / 4));
+    if (g->bx_ok) {
+        TRY(g->alloc(&g->xq, (size_t)D / 16 * 4 * 3 * 64));
+        TRY(g->alloc(&g->yq, (size_t)D / 16 * 4 * 3 * 64));
+        TRY(g->alloc(&g->hq, (size_t)F / 16 * 4 * 3 * 64));
+        if (rc == WMAR_OK && hipMemsetAsync(g->yq, 0, (size_t)D / 16 * 4 * 3 * 64 * 16, st) != hipSuccess) { set_error("rar_create: memset failed"); rc = WMAR_EHIP; }
+    }
     TRY(g->alloc(&g->mod, Mpad * (size_t)g->Ntot));
     TRY(g->alloc(&g->mod_u, (size_t)((g->T + 31) / 32) * 32 * (size_t)g->Ntot));
     TRY(g->alloc(&g->stats, (size_t)STAT_CHUNKS_MAX * Mpad * 2));
