@@ -1223,11 +1223,14 @@ struct BxArgs {
     long long slab_stride;     // float4 units
     int KU;                    // K / 16
     int S;                     // K slices: KU == 4 * PER * S
+    // GELU variant (S == 1): out is not written; gelu(sum + bias) goes out as bf16 pieces for the next k_bx GEMM
+    const float* bias;         // [N]
+    u32x4* outq;               // planes [N/16][MTW][3][64]
 };
 
 #define WMAR_BX_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
 
-template <int NT, int PER, int MTW = 2>
+template <int NT, int PER, int MTW = 2, bool GELU = false>
 __global__ __launch_bounds__(256) void k_bx(BxArgs a) {
     // MTW row tiles of 32 (2: 64 rows, 4: 128 rows -- RAR under guidance); planes [K/16][MTW][3][64], slabs packed [N/8][MTW][64]
     constexpr int XR = 3 * MTW;             // 16-byte operand loads of a step
@@ -1309,16 +1312,23 @@ __global__ __launch_bounds__(256) void k_bx(BxArgs a) {
         float4 v = red[0][row][lane];
 #pragma unroll
         for (int o = 1; o < 4; ++o) { const float4 q = red[o][row][lane]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-        out[((long long)((grp * NT + t) * 4 + g) * MTW + i) * 64 + lane] = v;
+        if (GELU) {
+            const int kb = (grp * NT + t) * 4 + g, hf = lane >> 5;          // output features 8 kb + 4 hf .. + 3 = the next GEMM's k
+            const float4 bb = *(const float4*)(a.bias + kb * 8 + 4 * hf);
+            v = make_float4(gelu_erf(v.x + bb.x), gelu_erf(v.y + bb.y), gelu_erf(v.z + bb.z), gelu_erf(v.w + bb.w));
+            bx_store_planes4(a.outq, MTW, kb, hf, i, lane & 31, v);
+        } else {
+            out[((long long)((grp * NT + t) * 4 + g) * MTW + i) * 64 + lane] = v;
+        }
     }
 }
 
 constexpr int BX_PER = 6;              // 16-k steps per wave: K slice = 4 waves x 6 x 16 = 384
 constexpr int BX_KSLICE = 4 * BX_PER * 16;
 // N must be a multiple of 32 * NT, K = S * 64 * PER; 32 * MTW rows
-template <int NT, int PER = BX_PER, int MTW = 2>
+template <int NT, int PER = BX_PER, int MTW = 2, bool GELU = false>
 static int launch_bx(const BxArgs& a, int N, hipStream_t st) {
-    hipLaunchKernelGGL((k_bx<NT, PER, MTW>), dim3((unsigned)(N / (32 * NT) * a.S)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_bx<NT, PER, MTW, GELU>), dim3((unsigned)(N / (32 * NT) * a.S)), dim3(256), 0, st, a);
     return launch_status("k_bx");
 }
 

@@ -213,7 +213,7 @@ static int launch_bx4(const BxArgs& a, int N, int PER, hipStream_t st) {
 
 struct RarLayer {
     float4 *wqkv, *wproj, *wfc1, *wfc2;
-    float4 *wqkv_bx = nullptr, *wproj_bx = nullptr, *wfc2_bx = nullptr;   // k_pack_bx order (128-row steps on the bf16 matrix pipe)
+    float4 *wqkv_bx = nullptr, *wproj_bx = nullptr, *wfc2_bx = nullptr, *wfc1_bx = nullptr;   // k_pack_bx order (128-row steps on the bf16 matrix pipe)
     float *bqkv, *bproj, *bfc1, *bfc2, *n1w, *n1b, *n2w, *n2b, *qnw, *qnb, *knw, *knb;
 };
 
@@ -232,6 +232,7 @@ struct wmar_rar {
     u32x4 *xq = nullptr, *yq = nullptr, *hq = nullptr;
     BxShape bx_qkv, bx_proj, bx_fc2;
     bool bx_ok = false, no_bx = false;
+    bool bx_fc1 = false;    // FC1 + bias + GELU as k_bx with the whole K per workgroup (K / 64 steps per wave: 20 at 1280)
     float* mod = nullptr;
     float* mod_u = nullptr;   // [T][Ntot] modulations of the unconditional row at every position (built on first guided generate)
     bool mod_u_ready = false;
@@ -379,11 +380,23 @@ struct RarPlan {
             if ((rc = gemm_split(p, &S, st, S_proj))) return rc;
         }
         if ((rc = resid(w.bproj, S_proj, o + 2 * D))) return rc;
+        const bool fc1x = bx && g->bx_fc1
+#ifdef WMAR_DEV_KNOBS
+                          && !getenv("WMAR_RAR_NO_FC1_BX")
+#endif
+            ;
+        if (fc1x) {
+            if ((rc = modulate(w.n2w, w.n2b, o + 3 * D, o + 4 * D, g->xq))) return rc;
+            BxArgs x{};
+            x.Wq = w.wfc1_bx; x.Xq = g->xq; x.KU = D / 16; x.S = 1; x.bias = w.bfc1; x.outq = g->hq;
+            if ((rc = launch_bx<1, 20, 4, true>(x, g->F, st))) return rc;
+        } else {
         if ((rc = modulate(w.n2w, w.n2b, o + 3 * D, o + 4 * D))) return rc;
         GemmArgs f = base();
         f.Wp = w.wfc1; f.Xp = g->h; f.bias = w.bfc1; f.KB = KBD; f.NT = g->F / 32; f.out_packed = g->hbuf;
         f.out_planes = bx ? g->hq : nullptr;
         if ((rc = gemm_dispatch<EPI_GELU, false>(f, false, st))) return rc;
+        }
         if (bx) {
             BxArgs x{};
             x.Wq = w.wfc2_bx; x.Xq = g->hq; x.out = g->slabs; x.slab_stride = act; x.KU = g->F / 16; x.S = g->bx_fc2.S;
@@ -460,6 +473,7 @@ int wmar_rar_create(const wmar_rar_config* cfg, const char* const* names, const 
     }
     if (g->MTmax >= 4 && D % 32 == 0 && F % 32 == 0) {
         g->bx_qkv = bx_shape(3 * D / 64, D / 16); g->bx_proj = bx_shape(D / 32, D / 16); g->bx_fc2 = bx_shape(D / 64, F / 16);
+        g->bx_fc1 = D == 1280 && F % 32 == 0 && F / 32 <= 256;
         g->bx_ok = D % 64 == 0 && g->bx_qkv.S > 0 && g->bx_qkv.S <= QKV_SLABS_MAX && g->bx_proj.S > 0 && g->bx_fc2.S > 0;
     }
 #ifdef WMAR_DEV_KNOBS
@@ -494,6 +508,7 @@ int wmar_rar_create(const wmar_rar_config* cfg, const char* const* names, const 
             TRY(g->alloc(&w.wqkv_bx, (size_t)3 * D * D / 4)); TRY(pack_bx(qw, w.wqkv_bx, 3 * D, D));
             TRY(g->alloc(&w.wproj_bx, (size_t)D * D / 4)); TRY(pack_bx(pw, w.wproj_bx, D, D));
             TRY(g->alloc(&w.wfc2_bx, (size_t)F * D / 4)); TRY(pack_bx(f2w, w.wfc2_bx, D, F));
+            if (g->bx_fc1) { TRY(g->alloc(&w.wfc1_bx, (size_t)F * D / 4)); TRY(pack_bx(f1w, w.wfc1_bx, F, D)); }
         }
         TRY(copy_vec(g, &w.n1w, n1w, (size_t)D, st)); TRY(copy_vec(g, &w.n1b, n1b, (size_t)D, st));
         TRY(copy_vec(g, &w.n2w, n2w, (size_t)D, st)); TRY(copy_vec(g, &w.n2b, n2b, (size_t)D, st));
