@@ -602,7 +602,7 @@ static __global__ __launch_bounds__(256) void k_fc1x(Fc1xArgs a) {
     };
 // One unit (16 k = 8 pairs x 6 MFMAs); the six loads of the unit three ahead ride one per pair behind a 16x16 MFMA: a wave issues
 // in order, so anything in front of an MFMA that is ready idles the matrix pipe.
-#define WMAR_FX_MMA(XC, WQ, W8V, XL, WQL, W8L, UNITL)                                            \
+#define WMAR_FX_MMA(XC, WQ, W8V, XL, WQL, W8L, UNITL, LOADQ)                                     \
     {                                                                                             \
         const int un_ = (UNITL);                                                                  \
         _Pragma("unroll") for (int pair = 0; pair < 8; ++pair) {                                  \
@@ -611,7 +611,7 @@ static __global__ __launch_bounds__(256) void k_fc1x(Fc1xArgs a) {
             const float b0 = j == 0 ? XC[kb][0].x : (j == 1 ? XC[kb][0].y : (j == 2 ? XC[kb][0].z : XC[kb][0].w)); \
             const float b1 = j == 0 ? XC[kb][1].x : (j == 1 ? XC[kb][1].y : (j == 2 ? XC[kb][1].z : XC[kb][1].w)); \
             fx16(acc16[0], b0, aq, pair & 1);                                                     \
-            if (!(FX_ABL & 1)) {                                                                  \
+            if (!(FX_ABL & 1) && (LOADQ)) {                                                       \
                 if (pair == 0) WQL = ld_nt(W16 + (long long)un_ * 64);                            \
                 if (pair == 1) W8L = ld_nt2(W8 + (long long)un_ * 64);                            \
                 if (pair >= 2 && pair < 6)                                                        \
@@ -639,14 +639,18 @@ static __global__ __launch_bounds__(256) void k_fc1x(Fc1xArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long tr1 = __builtin_amdgcn_s_memtime();
 #endif
-#define WMAR_FX_NEXT(I) WMAR_FX_UNIT((I) < per ? (I) : (I) - per)     /* past the end: an in-bounds re-read instead of a branch */
-    for (int it = 0; it < per; it += 4) {
-        WMAR_FX_MMA(xA, wqA, w8A, xD, wqD, w8D, WMAR_FX_NEXT(it + 3))
-        WMAR_FX_MMA(xB, wqB, w8B, xA, wqA, w8A, WMAR_FX_NEXT(it + 4))
-        WMAR_FX_MMA(xC, wqC, w8C, xB, wqB, w8B, WMAR_FX_NEXT(it + 5))
-        WMAR_FX_MMA(xD, wqD, w8D, xC, wqC, w8C, WMAR_FX_NEXT(it + 6))
+    int it = 0;
+    for (; it + 4 < per; it += 4) {
+        WMAR_FX_MMA(xA, wqA, w8A, xD, wqD, w8D, WMAR_FX_UNIT(it + 3), true)
+        WMAR_FX_MMA(xB, wqB, w8B, xA, wqA, w8A, WMAR_FX_UNIT(it + 4), true)
+        WMAR_FX_MMA(xC, wqC, w8C, xB, wqB, w8B, WMAR_FX_UNIT(it + 5), true)
+        WMAR_FX_MMA(xD, wqD, w8D, xC, wqC, w8C, WMAR_FX_UNIT(it + 6), true)
     }
-#undef WMAR_FX_NEXT
+    // the last four units: only the first still has a unit to request (nothing is read past the wave's K range)
+    WMAR_FX_MMA(xA, wqA, w8A, xD, wqD, w8D, WMAR_FX_UNIT(it + 3), true)
+    WMAR_FX_MMA(xB, wqB, w8B, xA, wqA, w8A, 0, false)
+    WMAR_FX_MMA(xC, wqC, w8C, xB, wqB, w8B, 0, false)
+    WMAR_FX_MMA(xD, wqD, w8D, xC, wqC, w8C, 0, false)
 #undef WMAR_FX_LOAD
 #undef WMAR_FX_MMA
 #undef WMAR_FX_UNIT
