@@ -1213,13 +1213,14 @@ static int launch_qkvx_bx(const QkvxArgs& q, int S_in, hipStream_t st) {
 }
 
 
-// ------------------------------------------------- plain split-K GEMM on the bf16 matrix pipe (64 rows; the output projection)
-// out[64 x N] = X W^T with X given as bf16 pieces (planes [K/16][2][3][64], written by the producer: bx_store_planes4) and W in
-// fp32 (k_pack_bx order), split in registers.  Workgroup = NT column tiles of 32 x one K slice of 384 (S = K / 384); its four waves
-// take 96 k each (PER = 6 steps of 16) for all 64 rows, and meet in LDS in a fixed order.  Slab s = raw partial sums of slice s in
-// the packed fp32 layout -- what k_resid_stats consumes.  A wave keeps ONE step of weights and of activation pieces in flight
-// beyond the one it computes on: more requests per CU than that queue at the memory pipeline and block the wave's in-order
-// issue, MFMAs included (scripts/stream_profile.hip, scripts/bx6_bench.hip).
+// ------------------------------------------------- plain split-K GEMM on the bf16 matrix pipe
+// out[32 MTW x N] = X W^T with X given as bf16 pieces (planes [K/16][MTW][3][64], written by the producer: bx_store_planes4) and W
+// in fp32 (k_pack_bx order), split in registers.  Workgroup = NT column tiles of 32 x one K slice of 64 PER; its four waves take
+// 16 PER k each for all rows, and meet in LDS in a fixed order.  Slab s = raw partial sums of slice s in the packed fp32 layout --
+// what k_resid_stats and the attention prologue consume -- or, with the whole K in one slice, gelu(sum + bias) as bf16 pieces for the
+// next k_bx.  Users: the Taming output projection (64 rows, 32 x 384 tiles), RAR's QKV / proj / FC1 / FC2 at 128 rows.
+// A wave keeps ONE step of weights and of activation pieces in flight beyond the one it computes on: more requests per CU than that
+// queue at the memory pipeline and block the wave's in-order issue, MFMAs included (scripts/stream_profile.hip, scripts/bx6_bench.hip).
 struct BxArgs {
     const float4* Wq;          // k_pack_bx layout
     const u32x4* Xq;           // activation planes [K/16][MTW][3][64]
