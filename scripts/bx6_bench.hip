@@ -111,9 +111,9 @@ struct BxArgs {
 #endif
 
 // Workgroup = (NT column tiles of 32) x (K slice blockIdx % S); its four waves split the slice's 16-k steps; slab s = raw partial sums.
-template <int NT, int PER>
-__global__ __launch_bounds__(256, BX_OCC) void k_bx6(BxArgs a) {
-    __shared__ __attribute__((aligned(16))) float4 red[4][NT * 8][64];
+template <int NT, int PER, int NW = 4>
+__global__ __launch_bounds__(NW * 64, BX_OCC) void k_bx6(BxArgs a) {
+    __shared__ __attribute__((aligned(16))) float4 red[NW][NT * 8][64];
     const unsigned long long te = __builtin_amdgcn_s_memtime();
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -207,14 +207,14 @@ __global__ __launch_bounds__(256, BX_OCC) void k_bx6(BxArgs a) {
             for (int g = 0; g < 4; ++g)
                 red[w][(t * 2 + i) * 4 + g][lane] = make_float4(acc[t][i][4 * g], acc[t][i][4 * g + 1], acc[t][i][4 * g + 2], acc[t][i][4 * g + 3]);
     __syncthreads();
-    // wave w sums rows w, w + 4, ... of the NT * 8 (tile, row tile, register group) rows over the four K quarters, in fixed order
+    // wave w sums rows w, w + NW, ... of the NT * 8 (tile, row tile, register group) rows over the NW K parts, in fixed order
     float4* out = a.out + (long long)ks * a.slab_stride;
 #pragma unroll
-    for (int r = 0; r < NT * 2; ++r) {
-        const int row = r * 4 + w, t = row >> 3, i = (row >> 2) & 1, g = row & 3;
+    for (int r = 0; r < NT * 8 / NW; ++r) {
+        const int row = r * NW + w, t = row >> 3, i = (row >> 2) & 1, g = row & 3;
         float4 v = red[0][row][lane];
 #pragma unroll
-        for (int o = 1; o < 4; ++o) { const float4 q = red[o][row][lane]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+        for (int o = 1; o < NW; ++o) { const float4 q = red[o][row][lane]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
         out[((long long)((grp * NT + t) * 4 + g) * 2 + i) * 64 + lane] = v;
     }
 #if BX_LAST
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, BX_OCC) void k_bx6(BxArgs a) {
     if (w == 0 && a.trace && lane == 0) { a.trace[blockIdx.x * 32] = te; a.trace[blockIdx.x * 32 + 1] = t0; a.trace[blockIdx.x * 32 + 2] = t1; a.trace[blockIdx.x * 32 + 3] = __builtin_amdgcn_s_memtime(); }
 }
 
-template <int NT, int PER>
+template <int NT, int PER, int NW = 4>
 static void run(const char* name, int N, int K, int S, hipStream_t st) {
     const int NL = 12;
     std::vector<float> hW((size_t)N * K), hX((size_t)64 * K);
@@ -306,10 +306,10 @@ static void run(const char* name, int N, int K, int S, hipStream_t st) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int rep = 0; rep < 4; ++rep) {
         (void)hipEventRecord(e0, st);
-        for (int l = 0; l < NL; ++l) { a.Wq = Wq[l]; hipLaunchKernelGGL((k_bx6<NT, PER>), dim3(grid), dim3(256), 0, st, a); }
+        for (int l = 0; l < NL; ++l) { a.Wq = Wq[l]; hipLaunchKernelGGL((k_bx6<NT, PER, NW>), dim3(grid), dim3(NW * 64), 0, st, a); }
         (void)hipEventRecord(e1, st); (void)hipStreamSynchronize(st);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-        if (rep == 3) printf("%s N=%d K=%d: %d workgroups of %d columns x %d k, ring %d: %.2f us per launch (%.1f MB -> %.2f TB/s)\n", name, N, K, grid, 32 * NT, K / S, BX_RING, ms * 1000.f / NL, N * (double)K * 4 / 1e6, N * (double)K * 4 / (ms * 1e-3 / NL) / 1e12);
+        if (rep == 3) printf("%s [%d waves] N=%d K=%d: %d workgroups of %d columns x %d k, ring %d: %.2f us per launch (%.1f MB -> %.2f TB/s)\n", name, NW, N, K, grid, 32 * NT, K / S, BX_RING, ms * 1000.f / NL, N * (double)K * 4 / 1e6, N * (double)K * 4 / (ms * 1e-3 / NL) / 1e12);
     }
     { std::vector<unsigned long long> h(grid * 32); (void)hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost);
       double av[3] = {0,0,0};
@@ -350,6 +350,26 @@ static void run(const char* name, int N, int K, int S, hipStream_t st) {
 
 int main() {
     hipStream_t st; (void)hipStreamCreate(&st);
+#ifdef BX_NW8
+    run<1, 24, 4>("fc1 n32 full K", 6144, 1536, 1, st);
+    run<1, 12, 8>("fc1 n32 full K", 6144, 1536, 1, st);
+    run<1, 6, 4>("proj", 1536, 1536, 4, st);
+    run<1, 3, 8>("proj", 1536, 1536, 4, st);
+    run<1, 4, 4>("proj", 1536, 1536, 6, st);
+    run<1, 2, 8>("proj", 1536, 1536, 6, st);
+    run<1, 24, 4>("fc2 n32 k1536", 1536, 6144, 4, st);
+    run<1, 12, 8>("fc2 n32 k1536", 1536, 6144, 4, st);
+    run<1, 16, 4>("fc2 n32 k1024", 1536, 6144, 6, st);
+    run<1, 8, 8>("fc2 n32 k1024", 1536, 6144, 6, st);
+    run<2, 12, 4>("fc2 n64 k768", 1536, 6144, 8, st);
+    run<2, 6, 8>("fc2 n64 k768", 1536, 6144, 8, st);
+    run<2, 6, 4>("qkv n64 k384", 4608, 1536, 4, st);
+    run<2, 3, 8>("qkv n64 k384", 4608, 1536, 4, st);
+    run<2, 12, 4>("qkv n64 k768", 4608, 1536, 2, st);
+    run<2, 6, 8>("qkv n64 k768", 4608, 1536, 2, st);
+    run<1, 12, 8>("qkv n32 whole K", 4608, 1536, 1, st);
+    return 0;
+#endif
     run<3, 6>("fc1", 6144, 1536, 4, st);
     run<3, 6>("fc2", 1536, 6144, 16, st);
     run<3, 6>("qkv", 4608, 1536, 4, st);

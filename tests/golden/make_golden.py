@@ -672,20 +672,151 @@ def spatial_vectors(args):
     print("wrote spatial_vectors.npz", os.path.getsize(os.path.join(HERE, "spatial_vectors.npz")), "bytes")
 
 
+def fullsize_vq_vectors(args):
+    """The three image tokenizers at the shapes the benchmarks run, from the reference's own
+    modules on seeded weights (synth.*_state(seed) regenerates them bit for bit wherever the fixture is used):
+      * Taming VQGAN f16/16384: ch 128, mult (1,1,2,2,4), 2 res blocks, attention at 16, 256 x 256, 16384 x 256 codebook
+        (deps/taming/modules/diffusionmodules/model.py:407-434, 507-538; deps/taming/modules/vqvae/quantize.py:272-331);
+      * MaskGIT-VQGAN of RAR at 256 x 256, 1024 codes (deps/rar/modeling/modules/maskgit_vqgan.py:157-362);
+      * Chameleon's VQGAN at 512 x 512, 8192 codes (deps/chameleon/inference/vqgan.py:330-570).
+    Stored per model: the codes, every 4th pixel of the decoded images (a different phase per image), the pre-quantisation vectors of
+    64 positions, the re-encoded codes with the reference's margin between the best and the second-best code (a code whose margin is
+    below the fp32 noise of the distance may legitimately differ), and for Taming the detector's p-values of both code sets."""
+    import torch
+    from deps.taming.modules.diffusionmodules.model import Decoder, Encoder
+    from deps.taming.modules.vqvae.quantize import VectorQuantizer2
+    from wmar.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
+    from wmar_amd.utils import synth
+
+    torch.set_num_threads(8)
+    out = {}
+    rs = np.random.RandomState(77)
+
+    def margins(z_flat, emb):
+        # quantize.py:279-283: d = sum z^2 + sum e^2 - 2 z e^T ; the two smallest distances per row
+        d = torch.sum(z_flat ** 2, dim=1, keepdim=True) + torch.sum(emb ** 2, dim=1) - 2 * torch.einsum("bd,dn->bn", z_flat, emb.t())
+        two = torch.topk(d, 2, dim=1, largest=False).values
+        return (two[:, 1] - two[:, 0]).numpy()
+
+    def sub(img):        # every 4th pixel, phase (b, 2b+1) for image b
+        return np.stack([img[b, :, (b % 4)::4, ((2 * b + 1) % 4)::4] for b in range(img.shape[0])])
+
+    # ---- Taming
+    vcfg = synth.TAMING_VQ
+    vsd = synth.synth_vq_state(vcfg, seed=31)
+    dd = dict(double_z=False, z_channels=vcfg.z_channels, resolution=vcfg.resolution, in_channels=3, out_ch=3, ch=vcfg.ch,
+              ch_mult=list(vcfg.ch_mult), num_res_blocks=vcfg.num_res_blocks, attn_resolutions=list(vcfg.attn_resolutions), dropout=0.0)
+    enc, dec = Encoder(**dd).eval(), Decoder(**dd).eval()
+    enc.load_state_dict({k[len("encoder."):]: v for k, v in vsd.items() if k.startswith("encoder.")}, strict=True)
+    dec.load_state_dict({k[len("decoder."):]: v for k, v in vsd.items() if k.startswith("decoder.")}, strict=True)
+    vq = VectorQuantizer2(vcfg.n_embed, vcfg.embed_dim, beta=0.25).eval()
+    vq.load_state_dict({"embedding.weight": vsd["quantize.embedding.weight"]}, strict=True)
+    qc = torch.nn.Conv2d(vcfg.z_channels, vcfg.embed_dim, 1)
+    pqc = torch.nn.Conv2d(vcfg.embed_dim, vcfg.z_channels, 1)
+    qc.load_state_dict({"weight": vsd["quant_conv.weight"], "bias": vsd["quant_conv.bias"]})
+    pqc.load_state_dict({"weight": vsd["post_quant_conv.weight"], "bias": vsd["post_quant_conv.bias"]})
+    S = vcfg.codes_size
+    codes = torch.from_numpy(rs.randint(0, vcfg.n_embed, size=(2, S * S)).astype(np.int64))
+    with torch.no_grad():
+        zq = vq.get_codebook_entry(codes.reshape(-1), shape=(2, S, S, vcfg.embed_dim))
+        img = dec(pqc(zq)).clamp(-1, 1)                                   # cond_transformer.py:186-192, taming_wrapper.py:79-84
+        h = qc(enc(img))
+        _, _, info = vq(h)
+        codes2 = info[2].view(2, -1)
+        zf = h.permute(0, 2, 3, 1).reshape(-1, vcfg.embed_dim)
+        out["tam_margin"] = margins(zf, vq.embedding.weight)
+    out["tam_codes"] = codes.numpy()
+    out["tam_pixels"] = sub(img.numpy())
+    out["tam_prequant"] = zf.numpy()[::8]
+    out["tam_codes_roundtrip"] = codes2.numpy()
+
+    def ids_file(name):
+        ids = []
+        for line in open(os.path.join(args.ref, "assets", name)):
+            ids.extend(int(t) for t in line.split(","))
+        return ids
+    alive = ids_file("vqgan_alive_ids.txt")
+    dead = list(set(range(16384)) - set(alive))
+    wm = GentimeWatermark({"alive_ids": torch.tensor(alive), "dead_ids": torch.tensor(dead), "embedding": torch.zeros(16384, 4)}, 16384,
+                          SeedStrategy.LINEAR, SplitStrategy.RANDOM_STRATIFIED, 1, 2.0, 0.25)
+    out["tam_pvals"] = wm.detect(codes).numpy()
+    out["tam_pvals_roundtrip"] = wm.detect(codes2).numpy()
+    print("taming full size: roundtrip l0 %.3f, min margin %.3e" % (float((codes2 != codes).float().mean()), float(out["tam_margin"].min())))
+
+    # ---- MaskGIT-VQGAN (RAR)
+    from deps.rar.modeling.modules.maskgit_vqgan import Decoder as MDecoder, Encoder as MEncoder, VectorQuantizer as MVQ
+
+    class AD(dict):
+        def __getattr__(self, k):
+            return self[k]
+
+        def get(self, k, d=None):
+            return dict.get(self, k, d)
+    mcfg = synth.MASKGIT_VQ
+    msd = synth.synth_maskgit_state(mcfg, seed=33)
+    tc = AD(channel_mult=list(mcfg.channel_mult), num_resolutions=mcfg.num_resolutions, dropout=0.0, hidden_channels=mcfg.hidden_channels,
+            num_channels=3, num_res_blocks=mcfg.num_res_blocks, resolution=mcfg.resolution, z_channels=mcfg.z_channels)
+    menc, mdec = MEncoder(tc).eval(), MDecoder(tc).eval()
+    mvq = MVQ(mcfg.num_embeddings, mcfg.z_channels, 0.25).eval()
+    menc.load_state_dict({k[8:]: v for k, v in msd.items() if k.startswith("encoder.")}, strict=True)
+    mdec.load_state_dict({k[8:]: v for k, v in msd.items() if k.startswith("decoder.")}, strict=True)
+    mvq.load_state_dict({"embedding.weight": msd["quantize.embedding.weight"]}, strict=True)
+    S = mcfg.codes_size
+    codes = torch.from_numpy(rs.randint(0, mcfg.num_embeddings, size=(2, S * S)).astype(np.int64))
+    with torch.no_grad():
+        img01 = torch.clamp(mdec(mvq.get_codebook_entry(codes)), 0.0, 1.0)          # titok.py:81-85
+        img = torch.clamp(img01 * 2.0 - 1.0, -1.0, 1.0)                              # rar_wrapper.py:112-114
+        h = menc((img + 1.0) / 2.0)                                                  # rar_wrapper.py:124-125
+        _, idx, _ = mvq(h)
+        zf = h.permute(0, 2, 3, 1).reshape(-1, mcfg.z_channels)
+        out["mg_margin"] = margins(zf, mvq.embedding.weight)
+    out["mg_codes"] = codes.numpy()
+    out["mg_pixels"] = sub(img.numpy())
+    out["mg_prequant"] = zf.numpy()[::8]
+    out["mg_codes_roundtrip"] = idx.view(2, -1).numpy().astype(np.int64)
+    print("maskgit full size: roundtrip l0 %.3f, min margin %.3e" % (float((idx.view(2, -1) != codes).float().mean()), float(out["mg_margin"].min())))
+
+    # ---- Chameleon VQGAN at 512 x 512 (one image)
+    from deps.chameleon.inference.vqgan import VQModel
+    ccfg = synth.CHAMELEON_VQ
+    csd = synth.synth_vq_state(ccfg, seed=35)
+    cvq = VQModel(ddconfig=dict(double_z=False, z_channels=ccfg.z_channels, resolution=ccfg.resolution, in_channels=3, out_ch=3, ch=ccfg.ch,
+                                ch_mult=list(ccfg.ch_mult), num_res_blocks=ccfg.num_res_blocks, attn_resolutions=[], dropout=0.0),
+                  n_embed=ccfg.n_embed, embed_dim=ccfg.embed_dim).eval()
+    cvq.load_state_dict(csd, strict=True)
+    S = ccfg.codes_size
+    codes = torch.from_numpy(rs.randint(0, ccfg.n_embed, size=(1, S * S)).astype(np.int64))
+    with torch.no_grad():
+        zq = cvq.quantize.get_codebook_entry(codes.view(-1), (1, S, S, ccfg.embed_dim))
+        img = cvq.decode(zq)                                                         # image_tokenizer.py:118-126 (no clamp in the model)
+        h = cvq.quant_conv(cvq.encoder(img))
+        _, _, (_, _, idx) = cvq.encode(img)
+        zf = h.permute(0, 2, 3, 1).reshape(-1, ccfg.embed_dim)
+        out["ch_margin"] = margins(zf, cvq.quantize.embedding.weight)
+    out["ch_codes"] = codes.numpy()
+    out["ch_pixels"] = sub(img.numpy())
+    out["ch_prequant"] = zf.numpy()[::16]
+    out["ch_codes_roundtrip"] = idx.view(1, -1).numpy().astype(np.int64)
+    print("chameleon full size: roundtrip l0 %.3f, min margin %.3e" % (float((idx.view(1, -1) != codes).float().mean()), float(out["ch_margin"].min())))
+    np.savez_compressed(os.path.join(HERE, "fullsize_vq_vectors.npz"), **out)
+    print("wrote fullsize_vq_vectors.npz", os.path.getsize(os.path.join(HERE, "fullsize_vq_vectors.npz")), "bytes")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--only", default="", help="'gumbel' / 'chameleon' / 'prod' / 'sampler' / 'harness' / 'spatial': regenerate only that fixture file")
+    ap.add_argument("--only", default="", help="'gumbel' / 'chameleon' / 'prod' / 'sampler' / 'harness' / 'spatial' / 'fullvq': regenerate only that fixture file")
     args = ap.parse_args()
     if args.only == "gumbel":
         gumbel_vectors(args)
         return
-    if args.only in ("chameleon", "prod", "sampler", "harness", "spatial"):
+    if args.only in ("chameleon", "prod", "sampler", "harness", "spatial", "fullvq"):
         tmp = tempfile.mkdtemp(prefix="wmar_stubs_")
         _stubs(tmp)
         sys.path[:0] = [tmp, args.ref, REPO]
         os.chdir(args.ref)
-        {"chameleon": chameleon_vectors, "prod": prod_vectors, "sampler": sampler_bulk_vectors, "harness": harness_vectors, "spatial": spatial_vectors}[args.only](args)
+        {"chameleon": chameleon_vectors, "prod": prod_vectors, "sampler": sampler_bulk_vectors, "harness": harness_vectors, "spatial": spatial_vectors,
+         "fullvq": fullsize_vq_vectors}[args.only](args)
         return
     tmp = tempfile.mkdtemp(prefix="wmar_stubs_")
     _stubs(tmp)
@@ -916,6 +1047,7 @@ def main():
     sz = os.path.getsize(os.path.join(HERE, "reference_vectors.npz"))
     print("wrote reference_vectors.npz", sz, "bytes; key_kat.json")
     spatial_vectors(args)
+    fullsize_vq_vectors(args)
     harness_vectors(args)      # last: it plants placeholder modules for generate.py's unrelated imports
 
 
