@@ -416,7 +416,8 @@ int wmar_cham_generate_image(wmar_cham* g, const wmar_wm_ctx* wm, const int64_t*
     a.logits = g->logits; a.V = V; a.past = g->ids; a.past_stride = ids_stride; a.t_dev = g->ctr + 2;
     a.temperature = sp->temperature; a.top_k = 0; a.use_top_p = sp->top_p >= 0; a.top_p_thr = (float)(1.0 - sp->top_p);
     a.q = q_dev; a.q_step_stride = (long long)B * V; a.step_dev = g->ctr + 1;
-    a.scratch = g->scratch; a.tok_out = (long long*)tokens_out_dev; a.tok_out_stride = n_tokens;
+    a.scratch = a.V > 65536 ? g->scratch : nullptr;   /* rows up to 65536 entries live in the sampler's registers */
+    a.tok_out = (long long*)tokens_out_dev; a.tok_out_stride = n_tokens;
     a.past_append = g->ids; a.trace = nullptr; a.B = B;
     a.logits_img = g->logits + (long long)B * V; a.logits_uncond = g->logits + 2ll * B * V;
     a.g_text = sp->guidance_scale_text; a.g_image = sp->guidance_scale_image; a.allow = allow_dev;

@@ -650,7 +650,8 @@ int wmar_gpt_generate(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_para
     a.temperature = sp->temperature; a.top_k = sp->top_k; a.use_top_p = sp->top_p >= 0;
     a.top_p_thr = (float)(1.0 - sp->top_p);
     a.q = q_dev; a.q_step_stride = (long long)B * g->V; a.step_dev = g->step_dev;
-    a.scratch = g->scratch; a.tok_out = (long long*)tokens_out_dev; a.tok_out_stride = steps;
+    a.scratch = a.V > 65536 ? g->scratch : nullptr;   /* rows up to 65536 entries live in the sampler's registers */
+    a.tok_out = (long long*)tokens_out_dev; a.tok_out_stride = steps;
     a.past_append = g->past; a.trace = logits_trace_dev; a.B = B;
     // sampler reads its length from pos_dev+... : length of past at step n is n+1 == pos+1.
     // k_sample_fused takes t from *t_dev, so point it at a dedicated counter kept at pos+1.

@@ -644,7 +644,8 @@ static int rar_generate_impl(wmar_rar* g, const wmar_wm_ctx* wm, const int64_t* 
     a.logits = g->logits; a.V = V; a.past = g->ids; a.past_stride = L; a.t_dev = g->ctr + 2;
     a.temperature = temperature; a.top_k = 0; a.use_top_p = 0; a.top_p_thr = 0.f;
     a.q = q_dev; a.q_step_stride = (long long)B * V; a.step_dev = g->ctr + 1;
-    a.scratch = g->scratch; a.tok_out = (long long*)tokens_out_dev; a.tok_out_stride = L;
+    a.scratch = a.V > 65536 ? g->scratch : nullptr;   /* rows up to 65536 entries live in the sampler's registers */
+    a.tok_out = (long long*)tokens_out_dev; a.tok_out_stride = L;
     a.past_append = g->ids; a.trace = nullptr; a.B = B;
     if (use_guidance) { a.logits_uncond = g->logits + (long long)B * V; a.cfg_scale = g->cfg_scale; }
     GumbelArgs ga{};

@@ -156,34 +156,52 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
         for (long long v = tid; v < V; v += SAMP_THREADS) { const float xv = x[v]; BODY }    \
     }
 
-    // P0: bias, temperature, row max
+    // P0: bias, temperature, row max.  The noise row is requested here as well when it fits beside the row (EPT <= 16): its
+    // latency then hides under the passes instead of being paid in front of the final argmax.
     uint32_t kmax = 0;
-    if (EPT > 0) {
-        float lv[EPT > 0 ? EPT : 1];
+    constexpr int QN = (EPT > 0 && EPT <= 16) ? EPT : 1;
+    float qpre[QN];
+    if (EPT > 0 && EPT <= 16) {
 #pragma unroll
-        for (int i = 0; i < (EPT > 0 ? EPT : 1); ++i) {
+        for (int i = 0; i < QN; ++i) {
             const long long v = tid + (long long)i * SAMP_THREADS;
-            const long long sv = v < V ? WMAR_SRC(v) : 0;
-            lv[i] = v < V ? lg[sv] : 0.f;
-            if (il && v < V) {
-                const float u = ul[sv], im = il[sv];
-                const float d1 = im - u; const float t1 = a.g_image * d1; const float s1 = u + t1;
-                const float d2 = lv[i] - im; const float t2 = a.g_text * d2; lv[i] = s1 + t2;
-            } else if (ul && v < V) { const float u = ul[sv]; const float dlt = lv[i] - u; const float sc = dlt * cfg; lv[i] = u + sc; }
+            qpre[i] = v < V ? q[WMAR_SRC(v)] : 1.f;
         }
+    }
+    if (EPT > 0) {
+        // chunks of 16 values per thread: all loads of a chunk are issued before its arithmetic (one round trip per chunk),
+        // without holding a second copy of a 64-value row in registers
+        constexpr int CH = EPT > 16 ? 16 : (EPT > 0 ? EPT : 1);
 #pragma unroll
-        for (int i = 0; i < (EPT > 0 ? EPT : 1); ++i) {
-            const long long v = tid + (long long)i * SAMP_THREADS;
-            if (v < V) {
-                float xv = lv[i];
-                const long long sv = WMAR_SRC(v);
-                if (trace) trace[sv] = xv;
-                if (grow && ((grow[sv >> 5] >> (sv & 31)) & 1u)) xv = xv + delta;
-                if (a.allow && !((a.allow[sv >> 5] >> (sv & 31)) & 1u)) xv = -INFINITY;
-                xv = xv / T;
-                x[v] = xv;
-                xr[i] = xv;
-                kmax = max(kmax, wmar_f32_key(xv));
+        for (int c0 = 0; c0 < (EPT > 0 ? EPT : 1); c0 += CH) {
+            float lv[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int i = c0 + j;
+                const long long v = tid + (long long)i * SAMP_THREADS;
+                const long long sv = v < V ? WMAR_SRC(v) : 0;
+                lv[j] = v < V ? lg[sv] : 0.f;
+                if (il && v < V) {
+                    const float u = ul[sv], im = il[sv];
+                    const float d1 = im - u; const float t1 = a.g_image * d1; const float s1 = u + t1;
+                    const float d2 = lv[j] - im; const float t2 = a.g_text * d2; lv[j] = s1 + t2;
+                } else if (ul && v < V) { const float u = ul[sv]; const float dlt = lv[j] - u; const float sc = dlt * cfg; lv[j] = u + sc; }
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int i = c0 + j;
+                const long long v = tid + (long long)i * SAMP_THREADS;
+                if (v < V) {
+                    float xv = lv[j];
+                    const long long sv = WMAR_SRC(v);
+                    if (trace) trace[sv] = xv;
+                    if (grow && ((grow[sv >> 5] >> (sv & 31)) & 1u)) xv = xv + delta;
+                    if (a.allow && !((a.allow[sv >> 5] >> (sv & 31)) & 1u)) xv = -INFINITY;
+                    xv = xv / T;
+                    xr[i] = xv;                  // the row lives in registers; `scratch` gets a copy only when the caller asks for one
+                    if (a.scratch) x[v] = xv;
+                    kmax = max(kmax, wmar_f32_key(xv));
+                }
             }
         }
     } else {
@@ -350,25 +368,29 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
     const float Sf2 = wmar_fx_to_f32(S2);
     float best = -INFINITY;
     int besti = 0;
-    float qv[EPT > 0 ? EPT : 1];
     if (EPT > 0) {
+        constexpr int CH = EPT > 16 ? 16 : (EPT > 0 ? EPT : 1);
 #pragma unroll
-        for (int i = 0; i < (EPT > 0 ? EPT : 1); ++i) {
-            const long long v = tid + (long long)i * SAMP_THREADS;
-            qv[i] = v < V ? q[WMAR_SRC(v)] : 1.f;
-        }
-    }
-    if (EPT > 0) {
+        for (int c0 = 0; c0 < (EPT > 0 ? EPT : 1); c0 += CH) {
+            float qv[CH];
 #pragma unroll
-        for (int i = 0; i < (EPT > 0 ? EPT : 1); ++i) {
-            const long long v = tid + (long long)i * SAMP_THREADS;
-            if (v < V) {
-                const float xv = xr[i];
-                const uint32_t k = wmar_f32_key(xv);
-                const bool kept = k >= thr_key && (k > bkey || (k == bkey && v >= bidx));
-                const float e = kept ? wmar_expf(xv - m) : 0.0f;
-                const float r = (e / Sf2) / qv[i];
-                if (r > best) { best = r; besti = (int)v; }
+            for (int j = 0; j < CH; ++j) {
+                const long long v = tid + (long long)(c0 + j) * SAMP_THREADS;
+                if (EPT <= 16) qv[j] = qpre[(c0 + j) % QN];
+                else qv[j] = v < V ? q[WMAR_SRC(v)] : 1.f;
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int i = c0 + j;
+                const long long v = tid + (long long)i * SAMP_THREADS;
+                if (v < V) {
+                    const float xv = xr[i];
+                    const uint32_t k = wmar_f32_key(xv);
+                    const bool kept = k >= thr_key && (k > bkey || (k == bkey && v >= bidx));
+                    const float e = kept ? wmar_expf(xv - m) : 0.0f;
+                    const float r = (e / Sf2) / qv[j];
+                    if (r > best) { best = r; besti = (int)v; }
+                }
             }
         }
     } else {
