@@ -97,11 +97,14 @@ static __global__ __launch_bounds__(256) void k_rar_embed(RarEmbedArgs a) {
 
 // h = LayerNorm(x; gamma, beta, eps 1e-6) * (1 + scale) + shift      (modulate, rar.py:120-121)
 // gamma/beta null: no affine (FinalLayer.norm_final).  scale/shift: row-major [M][mod_stride].
+// The per-row modulations (shift / scale / gate of every block) come out of the adaLN GEMM in the PACKED activation layout
+// [Ntot/8][MTm][64] float4 -- the same (row = lane % 32, 4 features by lane / 32) mapping as x, so a wave reads them with one
+// coalesced 1-KiB load per k-block (row-major [M][Ntot] rows are 1 MB apart: 32 cache lines per load).
 struct ModArgs {
     const float4* x; float4* h; const double* stats;
     const float* gamma; const float* beta;
-    const float* shift; const float* scale; long long mod_stride;
-    const float* shift_u; const float* scale_u;   // nullable: rows >= split share row *pos_dev of the [T][mod_stride] table
+    const float4* modp; int MTm; long long kb_shift, kb_scale;   // packed modulations, their row tiles, k-block offsets of this shift / scale
+    const float* shift_u; const float* scale_u; long long mod_stride;   // nullable: rows >= split share row *pos_dev of the row-major [T][mod_stride] table
     const int* pos_dev; int split;
     int KB, MT, n_chunks, K;
     u32x4* hq;      // nullable: write the modulated rows as bf16 pieces (a k_bx GEMM follows) instead of h
@@ -114,9 +117,7 @@ static __global__ __launch_bounds__(256) void k_modulate(ModArgs a) {
     const int kb1 = (int)((unsigned)(c + 1) * (unsigned)a.KB / (unsigned)a.n_chunks);
     const int m = mt * 32 + (lane & 31), half = lane >> 5;
     const bool shared = a.shift_u && m >= a.split;
-    const long long mrow = shared ? (long long)(*a.pos_dev) * a.mod_stride : (long long)m * a.mod_stride;
-    const float* scale = (shared ? a.scale_u : a.scale) + mrow;
-    const float* shift = (shared ? a.shift_u : a.shift) + mrow;
+    const long long urow = (long long)(*a.pos_dev) * a.mod_stride;
     // every load of this wave's (up to) four k-blocks is issued before the first use: one round trip, not four
     constexpr int KPW = 4;   // the host keeps chunks at <= 16 k-blocks (stat_chunks)
     float4 v[KPW], g4[KPW], b4[KPW], sc[KPW], sh[KPW];
@@ -127,8 +128,13 @@ static __global__ __launch_bounds__(256) void k_modulate(ModArgs a) {
         v[i] = a.x[((long long)kb * a.MT + mt) * 64 + lane];
         g4[i] = a.gamma ? *(const float4*)(a.gamma + k) : make_float4(1.f, 1.f, 1.f, 1.f);
         b4[i] = a.gamma ? *(const float4*)(a.beta + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        sc[i] = *(const float4*)(scale + k);
-        sh[i] = *(const float4*)(shift + k);
+        if (shared) {
+            sc[i] = *(const float4*)(a.scale_u + urow + k);
+            sh[i] = *(const float4*)(a.shift_u + urow + k);
+        } else {
+            sc[i] = a.modp[((a.kb_scale + kb) * a.MTm + mt) * 64 + lane];
+            sh[i] = a.modp[((a.kb_shift + kb) * a.MTm + mt) * 64 + lane];
+        }
     }
     __builtin_amdgcn_sched_barrier(0);   // the row statistics are fetched while the data loads are in flight
     float mu, rstd;
@@ -160,6 +166,158 @@ static __global__ __launch_bounds__(256) void k_modulate(ModArgs a) {
         if (a.hq) bx_store_planes4(a.hq, a.MT, kb, half, mt, lane & 31, hv);
         else a.h[((long long)kb * a.MT + mt) * 64 + lane] = hv;
     }
+}
+
+// ------------------------------------------------------------------ gated residual + adaLN modulation in ONE launch
+// x' = x + gate * (bias + sum_s slab[s])  (k_resid_stats), then  h = LayerNorm(x'; eps 1e-6) * (1 + scale) + shift  (k_modulate) of the
+// SAME rows: the modulation needs the statistics of whole rows, i.e. of all n_chunks workgroups of a row tile.  They are tiny (32 rows
+// x 16 bytes per workgroup), so instead of a second launch (~5 us in the captured step, twice per block) every workgroup publishes
+// its partial sums with agent-scope 8-byte atomic stores into a buffer of its own launch site that a memset node poisoned (all ones:
+// a NaN no sum can produce) at the start of the position -- the data is the flag -- and polls the other chunks' words of its row tile
+// with agent-scope loads until none is poison (at most 64 x 4 workgroups of 256 threads: all resident), then modulates its OWN chunk,
+// still in registers.  Summation order is the chunk order (fixed): bit-identical to the two-launch path.
+struct ResidModArgs {
+    ResidArgs r;                                            // (its row-major gate fields are not used here)
+    const float* gamma; const float* beta;                 // nullable: no affine (FinalLayer.norm_final)
+    const float4* modp; int MTm; long long kb_gate, kb_shift, kb_scale;   // packed modulations (see ModArgs)
+    const float* gate_u; const float* shift_u; const float* scale_u; long long mod_stride; int split;   // nullable: shared rows (see ModArgs)
+    float4* h; u32x4* hq;                                   // output: packed fp32 rows, or bf16 pieces (a k_bx GEMM follows)
+    unsigned long long* part;                               // [n_chunks][Mpad][2] fp64 bit patterns of THIS launch site, poisoned (all ones) at the start of the position
+    unsigned* fail;                                         // set if a wait gives up (never on a healthy device)
+};
+
+// KPW = k-blocks per wave: 1 for the usual widths (a chunk = 4 k-blocks: 4 x as many workgroups as k_resid_stats' 16-block chunks -- the
+// launch is bound by each workgroup's read of its slab chunk from the other XCDs' L2 / the memory-side cache), 4 beyond 2048 features.
+template <int S, int KPW>
+__global__ __launch_bounds__(256) void k_resid_mod(ResidModArgs a) {
+    __shared__ double red[4][32][2];
+    __shared__ double grp[8][32][2];
+    __shared__ float s_mu[32], s_rs[32];
+    const ResidArgs& r = a.r;
+    const int c = blockIdx.x / r.MT, mt = blockIdx.x % r.MT;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int kb0 = (int)((long long)c * r.KB / r.n_chunks), kb1 = (int)((long long)(c + 1) * r.KB / r.n_chunks);
+    const int m = mt * 32 + (lane & 31), half = lane >> 5;
+    const int Mpad = r.MT * 32;
+    const bool shared = a.shift_u && m >= a.split;
+    const long long urow = (long long)(*r.pos_dev) * a.mod_stride;
+    // every operand of both phases is requested before the first use
+    float4 v[KPW], bb[KPW], sl[KPW][S], gg[KPW], g4[KPW], b4[KPW], sc[KPW], sh[KPW];
+    int kbs[KPW];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        const int kb = kb0 + w + 4 * i;
+        kbs[i] = kb < kb1 ? kb : -1;
+        const int kk = kb < kb1 ? kb : kb0;
+        const long long idx = ((long long)kk * r.MT + mt) * 64 + lane;
+        const int k = kk * 8 + 4 * half;
+        v[i] = r.x[idx];
+        bb[i] = *(const float4*)(r.bias + k);
+#pragma unroll
+        for (int si = 0; si < S; ++si) sl[i][si] = r.slabs[(long long)si * r.slab_stride + idx];
+        g4[i] = a.gamma ? *(const float4*)(a.gamma + k) : make_float4(1.f, 1.f, 1.f, 1.f);
+        b4[i] = a.gamma ? *(const float4*)(a.beta + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (shared) {
+            gg[i] = *(const float4*)(a.gate_u + urow + k);
+            sc[i] = *(const float4*)(a.scale_u + urow + k);
+            sh[i] = *(const float4*)(a.shift_u + urow + k);
+        } else {
+            gg[i] = a.modp[((a.kb_gate + kk) * a.MTm + mt) * 64 + lane];
+            sc[i] = a.modp[((a.kb_scale + kk) * a.MTm + mt) * 64 + lane];
+            sh[i] = a.modp[((a.kb_shift + kk) * a.MTm + mt) * 64 + lane];
+        }
+    }
+    double s = 0.0, ss = 0.0;
+    float4 rv[KPW];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kbs[i] < 0) continue;
+        float4 acc = sl[i][0];
+#pragma unroll
+        for (int si = 1; si < S; ++si) { acc.x += sl[i][si].x; acc.y += sl[i][si].y; acc.z += sl[i][si].z; acc.w += sl[i][si].w; }
+        const float4 x = make_float4(v[i].x + gg[i].x * (bb[i].x + acc.x), v[i].y + gg[i].y * (bb[i].y + acc.y),
+                                     v[i].z + gg[i].z * (bb[i].z + acc.z), v[i].w + gg[i].w * (bb[i].w + acc.w));
+        rv[i] = x;
+        r.x[((long long)kbs[i] * r.MT + mt) * 64 + lane] = x;
+        s += (double)x.x + (double)x.y + (double)x.z + (double)x.w;
+        ss += (double)x.x * x.x + (double)x.y * x.y + (double)x.z * x.z + (double)x.w * x.w;
+    }
+    s += __shfl_xor(s, 32);
+    ss += __shfl_xor(ss, 32);
+    if (lane < 32) { red[w][lane][0] = s; red[w][lane][1] = ss; }
+    __syncthreads();
+    constexpr unsigned long long POISON = ~0ull;
+    if (w == 0 && lane < 32) {
+        double ts = 0, tss = 0;
+        for (int i = 0; i < 4; ++i) { ts += red[i][lane][0]; tss += red[i][lane][1]; }
+        unsigned long long* o = a.part + ((long long)c * Mpad + mt * 32 + lane) * 2;
+        __hip_atomic_store(o, (unsigned long long)__double_as_longlong(ts), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 1, (unsigned long long)__double_as_longlong(tss), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    {
+        // row statistics of this tile's rows: thread (row = lane % 32, group = 2 w + lane / 32) re-reads the words of chunks group,
+        // group + 8, ... (its own chunk's included: an L2 round trip) until none is poison; group sums in chunk order, then the eight
+        // groups in group order: a fixed summation order
+        const int row = lane & 31, gq = 2 * w + (lane >> 5);
+        unsigned long long t0[8], t1[8];
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int cc = gq + 8 * i;
+                if (cc < r.n_chunks) {
+                    const unsigned long long* q = a.part + ((long long)cc * Mpad + mt * 32 + row) * 2;
+                    t0[i] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    t1[i] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok && t0[i] != POISON && t1[i] != POISON;
+                }
+            }
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 20)) { *a.fail = 1u; break; }
+        }
+        double sm = 0, sq = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (gq + 8 * i < r.n_chunks) { sm += __longlong_as_double((long long)t0[i]); sq += __longlong_as_double((long long)t1[i]); }
+        grp[gq][row][0] = sm; grp[gq][row][1] = sq;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double sm = 0, sq = 0;
+        for (int q = 0; q < 8; ++q) { sm += grp[q][threadIdx.x][0]; sq += grp[q][threadIdx.x][1]; }
+        const double invK = 1.0 / (double)r.K;
+        const double mean = sm * invK;
+        s_mu[threadIdx.x] = (float)mean;
+        s_rs[threadIdx.x] = rsqrtf((float)(sq * invK - mean * mean) + 1e-6f);
+    }
+    __syncthreads();
+    const float mu = s_mu[lane & 31], rstd = s_rs[lane & 31];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        if (kbs[i] < 0) continue;
+        float q[4] = {(rv[i].x - mu) * rstd, (rv[i].y - mu) * rstd, (rv[i].z - mu) * rstd, (rv[i].w - mu) * rstd};
+        if (a.gamma) {
+            q[0] = q[0] * g4[i].x + b4[i].x; q[1] = q[1] * g4[i].y + b4[i].y; q[2] = q[2] * g4[i].z + b4[i].z; q[3] = q[3] * g4[i].w + b4[i].w;
+        }
+        const float4 hv = make_float4(q[0] * (1.0f + sc[i].x) + sh[i].x, q[1] * (1.0f + sc[i].y) + sh[i].y,
+                                      q[2] * (1.0f + sc[i].z) + sh[i].z, q[3] * (1.0f + sc[i].w) + sh[i].w);
+        if (a.hq) bx_store_planes4(a.hq, r.MT, kbs[i], half, mt, lane & 31, hv);
+        else a.h[((long long)kbs[i] * r.MT + mt) * 64 + lane] = hv;
+    }
+}
+
+static int launch_resid_mod(const ResidModArgs& a, int grid, int kpw, hipStream_t st) {
+    switch (a.r.S) {
+#define WMAR_RM_CASE(N) case N: if (kpw == 1) hipLaunchKernelGGL((k_resid_mod<N, 1>), dim3(grid), dim3(256), 0, st, a); \
+                                else hipLaunchKernelGGL((k_resid_mod<N, 4>), dim3(grid), dim3(256), 0, st, a); break;
+        WMAR_RM_CASE(1) WMAR_RM_CASE(2) WMAR_RM_CASE(3) WMAR_RM_CASE(4) WMAR_RM_CASE(5) WMAR_RM_CASE(6) WMAR_RM_CASE(7) WMAR_RM_CASE(8)
+#undef WMAR_RM_CASE
+        default: set_error("resid_mod: bad slab count %d", a.r.S); return WMAR_EINVAL;
+    }
+    return launch_status("k_resid_mod");
 }
 
 // SiLU(emb[cond] + timesteps[p]) for p = 0..T-1 in packed layout: the adaLN input of a row whose
@@ -240,6 +398,9 @@ struct wmar_rar {
     float *kcache = nullptr, *vcache = nullptr, *logits = nullptr, *scratch = nullptr, *cfg_scale = nullptr;
     long long *ids = nullptr, *cond_ids = nullptr;
     int* ctr = nullptr;   // [pos, step, len]
+    unsigned long long* part = nullptr;   // [2 L launch sites][STAT_CHUNKS_MAX][Mpad][2]: k_resid_mod's published partial sums, poisoned at the start of every position
+    size_t part_site = 0;                 // words per site
+    unsigned* sync_fail = nullptr;
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev = nullptr;
     hipGraph_t graph = nullptr;
@@ -305,42 +466,57 @@ struct RarPlan {
     int adaln() {
         GemmArgs a = base();
         a.Wp = g->wada; a.Xp = g->sc; a.KB = KBD; a.NT = (int)(g->Ntot / 32); a.bias = g->bada;
-        a.logits = g->mod; a.V = (int)g->Ntot;
+        a.out_packed = (float4*)g->mod; a.slab_stride = 0;        // packed [Ntot/8][MTc][64]: read like an activation by k_modulate / k_resid_mod
         if (shared_u) { a.MT = MTc; a.B = Bhalf; }
-        return gemm_dispatch<EPI_LOGITS, false>(a, false, st);
+        return gemm_dispatch<EPI_PACKED, false>(a, false, st);
     }
     int modulate(const float* gamma, const float* beta, long long off_shift, long long off_scale, u32x4* planes = nullptr) {
         ModArgs m{};
         m.hq = planes;
         m.x = g->x; m.h = g->h; m.stats = g->stats; m.gamma = gamma; m.beta = beta;
-        m.shift = g->mod + off_shift; m.scale = g->mod + off_scale; m.mod_stride = g->Ntot;
+        m.modp = (const float4*)g->mod; m.MTm = MTc; m.kb_shift = off_shift / 8; m.kb_scale = off_scale / 8; m.mod_stride = g->Ntot;
         if (shared_u) { m.shift_u = g->mod_u + off_shift; m.scale_u = g->mod_u + off_scale; m.split = Bhalf; }
         m.pos_dev = g->ctr;
         m.KB = KBD; m.MT = MT; m.n_chunks = nch; m.K = D;
         hipLaunchKernelGGL(k_modulate, dim3(nch * MT), dim3(256), 0, st, m);
         return launch_status("k_modulate");
     }
-    int resid(const float* bias, int S, long long off_gate) {
-        ResidArgs r{};
-        r.x = g->x; r.stats = g->stats; r.KB = KBD; r.MT = MT; r.n_chunks = nch; r.B = M; r.K = D;
+    // gated residual fold of the S slabs in g->slabs + the adaLN modulation of the new rows for the NEXT GEMM (one launch)
+    int resid_mod(int site, const float* bias, int S, long long off_gate, const float* gamma, const float* beta, long long off_shift,
+                  long long off_scale, u32x4* planes) {
+        ResidModArgs a{};
+        ResidArgs& r = a.r;
+        const int kpw = KBD <= 256 ? 1 : 4, nrm = (KBD + 4 * kpw - 1) / (4 * kpw);      // chunks of 4 (or 16) k-blocks: <= 64 per row tile
+        r.x = g->x; r.stats = g->stats; r.KB = KBD; r.MT = MT; r.n_chunks = nrm; r.B = M; r.K = D;
         r.slabs = g->slabs; r.slab_stride = act; r.S = S; r.bias = bias;
-        r.gate = g->mod + off_gate; r.gate_stride = g->Ntot; r.pos_dev = g->ctr;
-        if (shared_u) { r.gate_u = g->mod_u + off_gate; r.gate_split = Bhalf; }
-        return launch_resid(r, nch * MT, st);
+        r.pos_dev = g->ctr;
+        a.gamma = gamma; a.beta = beta; a.modp = (const float4*)g->mod; a.MTm = MTc;
+        a.kb_gate = off_gate / 8; a.kb_shift = off_shift / 8; a.kb_scale = off_scale / 8; a.mod_stride = g->Ntot;
+        if (shared_u) { a.gate_u = g->mod_u + off_gate; a.shift_u = g->mod_u + off_shift; a.scale_u = g->mod_u + off_scale; a.split = Bhalf; }
+        a.h = g->h; a.hq = planes;
+        a.part = g->part + (size_t)site * g->part_site; a.fail = g->sync_fail;
+        return launch_resid_mod(a, nrm * MT, kpw, st);
     }
+    bool fc1_bx() const {
+        return bx && g->bx_fc1
+#ifdef WMAR_DEV_KNOBS
+               && !getenv("WMAR_RAR_NO_FC1_BX")
+#endif
+            ;
+    }
+    // The block's input rows arrive already modulated for the QKV projection (planes in g->xq when bx, else fp32 in g->h): by the
+    // position's first k_modulate (block 0) or by the previous block's second k_resid_mod.
     int layer(int l) {
         const RarLayer& w = g->layers[l];
         const long long o = (long long)l * 6 * D;   // chunk(6): shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
         int rc, S = 1;
         int S_qkv = 1;
         if (bx) {
-            if ((rc = modulate(w.n1w, w.n1b, o, o + D, g->xq))) return rc;
             BxArgs x{};
             x.Wq = w.wqkv_bx; x.Xq = g->xq; x.out = g->qkv_slabs; x.slab_stride = 3 * act; x.KU = D / 16; x.S = g->bx_qkv.S;
             if ((rc = launch_bx4<2>(x, 3 * D, g->bx_qkv.PER, st))) return rc;     // 64-column groups: half the activation reads per column
             S_qkv = g->bx_qkv.S;
         } else {
-            if ((rc = modulate(w.n1w, w.n1b, o, o + D))) return rc;
             GemmArgs a = base();
             a.Wp = w.wqkv; a.Xp = g->h; a.KB = KBD; a.NT = 3 * D / 32; a.out_packed = g->qkv_slabs; a.slab_stride = 3 * act;
             if ((rc = gemm_split(a, &S, st, 1))) return rc;
@@ -379,23 +555,18 @@ struct RarPlan {
             p.Wp = w.wproj; p.Xp = g->y; p.KB = KBD; p.NT = D / 32; p.out_packed = g->slabs; p.slab_stride = act;
             if ((rc = gemm_split(p, &S, st, S_proj))) return rc;
         }
-        if ((rc = resid(w.bproj, S_proj, o + 2 * D))) return rc;
-        const bool fc1x = bx && g->bx_fc1
-#ifdef WMAR_DEV_KNOBS
-                          && !getenv("WMAR_RAR_NO_FC1_BX")
-#endif
-            ;
+        const bool fc1x = fc1_bx();
+        // x += gate_msa * (proj + bias);  norm2 + modulate(shift_mlp, scale_mlp) -> the FC1 operand
+        if ((rc = resid_mod(2 * l, w.bproj, S_proj, o + 2 * D, w.n2w, w.n2b, o + 3 * D, o + 4 * D, fc1x ? g->xq : nullptr))) return rc;
         if (fc1x) {
-            if ((rc = modulate(w.n2w, w.n2b, o + 3 * D, o + 4 * D, g->xq))) return rc;
             BxArgs x{};
             x.Wq = w.wfc1_bx; x.Xq = g->xq; x.KU = D / 16; x.S = 1; x.bias = w.bfc1; x.outq = g->hq;
             if ((rc = launch_bx<1, 20, 4, true>(x, g->F, st))) return rc;
         } else {
-        if ((rc = modulate(w.n2w, w.n2b, o + 3 * D, o + 4 * D))) return rc;
-        GemmArgs f = base();
-        f.Wp = w.wfc1; f.Xp = g->h; f.bias = w.bfc1; f.KB = KBD; f.NT = g->F / 32; f.out_packed = g->hbuf;
-        f.out_planes = bx ? g->hq : nullptr;
-        if ((rc = gemm_dispatch<EPI_GELU, false>(f, false, st))) return rc;
+            GemmArgs f = base();
+            f.Wp = w.wfc1; f.Xp = g->h; f.bias = w.bfc1; f.KB = KBD; f.NT = g->F / 32; f.out_packed = g->hbuf;
+            f.out_planes = bx ? g->hq : nullptr;
+            if ((rc = gemm_dispatch<EPI_GELU, false>(f, false, st))) return rc;
         }
         if (bx) {
             BxArgs x{};
@@ -406,20 +577,29 @@ struct RarPlan {
             q.Wp = w.wfc2; q.Xp = g->hbuf; q.KB = KBF; q.NT = D / 32; q.out_packed = g->slabs; q.slab_stride = act;
             if ((rc = gemm_split(q, &S, st, S_fc2))) return rc;
         }
-        return resid(w.bfc2, S_fc2, o + 5 * D);
+        // x += gate_mlp * (FC2 + bias);  then the NEXT consumer's modulation: block l+1's norm1 (shift_msa, scale_msa), or the
+        // FinalLayer's affine-free norm (scale first, then shift: rar.py:132) into fp32 rows for the vocabulary head
+        if (l + 1 < g->L) {
+            const RarLayer& nx = g->layers[l + 1];
+            const long long o2 = o + 6 * D;
+            return resid_mod(2 * l + 1, w.bfc2, S_fc2, o + 5 * D, nx.n1w, nx.n1b, o2, o2 + D, bx ? g->xq : nullptr);
+        }
+        const long long of = (long long)g->L * 6 * D;
+        return resid_mod(2 * l + 1, w.bfc2, S_fc2, o + 5 * D, nullptr, nullptr, of + D, of, nullptr);
     }
     int head(float* logits_out) {
-        const long long o = (long long)g->L * 6 * D;   // FinalLayer: scale first, then shift (rar.py:132)
-        int rc;
-        if ((rc = modulate(nullptr, nullptr, o + D, o))) return rc;
         GemmArgs a = base();
         a.Wp = g->whead; a.Xp = g->h; a.KB = KBD; a.NT = g->V / 32; a.bias = g->bhead; a.logits = logits_out; a.V = g->V;
         return gemm_dispatch<EPI_LOGITS, false>(a, false, st);
     }
     int position(bool with_head, float* logits_out) {
         int rc;
+        if (hipMemsetAsync(g->part, 0xff, (size_t)2 * g->L * g->part_site * 8, st) != hipSuccess) {     // poison: "not published yet"
+            set_error("rar position: poisoning the partial sums failed"); return WMAR_EHIP;
+        }
         if ((rc = embed())) return rc;
         if ((rc = adaln())) return rc;
+        { const RarLayer& w0 = g->layers[0]; if ((rc = modulate(w0.n1w, w0.n1b, 0, D, bx ? g->xq : nullptr))) return rc; }
         for (int l = 0; l < g->L; ++l)
             if ((rc = layer(l))) return rc;
         return with_head ? head(logits_out) : WMAR_OK;
@@ -552,6 +732,9 @@ int wmar_rar_create(const wmar_rar_config* cfg, const char* const* names, const 
     TRY(g->alloc(&g->ids, (size_t)g->Bmax * cfg->image_seq_len));
     TRY(g->alloc(&g->cond_ids, (size_t)g->Mmax));
     TRY(g->alloc(&g->ctr, 4));
+    { const int kbd = D / 8, kpw = kbd <= 256 ? 1 : 4; g->part_site = (size_t)((kbd + 4 * kpw - 1) / (4 * kpw)) * g->MTmax * 32 * 2; }
+    TRY(g->alloc(&g->part, (size_t)2 * L * g->part_site));
+    TRY(g->alloc(&g->sync_fail, 4));
     if (rc == WMAR_OK) {
         hipError_t er = hipMemsetAsync(g->x, 0, Mpad * D * 4, st);
         if (er == hipSuccess) er = hipMemsetAsync(g->h, 0, Mpad * D * 4, st);
