@@ -177,6 +177,9 @@ int wmar_gpt_set_attention_phases(wmar_gpt* g, int32_t one_wave_upto, int32_t tw
  * launch boundary included.  kv_len = cached rows the attention role reads. */
 int wmar_gpt_profile_role(wmar_gpt* g, int32_t role, int64_t B, int32_t kv_len, int32_t iters, void* stream,
                           double* avg_us);
+/* The kernels a decode step of B rows launches per role, as `role=kernel;...` text (bench.py names what it measured from this, not
+ * from a table of its own).  Returns WMAR_EINVAL if buf is too small. */
+int wmar_gpt_plan_info(wmar_gpt* g, int64_t B, char* buf, int64_t buf_len);
 /* total_us[c], calls[c] for each class; *step_ms = average wall time of one decode step (any mode). */
 int wmar_gpt_get_timing(wmar_gpt* g, double* total_us, int64_t* calls, double* step_ms);
 

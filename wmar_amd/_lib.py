@@ -17,7 +17,7 @@ SYMBOLS = [
     "wmar_last_error", "wmar_version", "wmar_key_row_words", "wmar_key_table_rows", "wmar_key_table_build",
     "wmar_key_greenlist", "wmar_wm_process_logits", "wmar_sample_fused", "wmar_detect", "wmar_detect_num_ngrams",
     "wmar_gpt_create", "wmar_gpt_destroy", "wmar_gpt_device_bytes", "wmar_gpt_decode_step", "wmar_gpt_generate",
-    "wmar_gpt_set_timing", "wmar_gpt_set_attention_phases", "wmar_gpt_get_timing", "wmar_gpt_profile_role", "wmar_rar_create", "wmar_rar_destroy",
+    "wmar_gpt_set_timing", "wmar_gpt_set_attention_phases", "wmar_gpt_get_timing", "wmar_gpt_profile_role", "wmar_gpt_plan_info", "wmar_rar_create", "wmar_rar_destroy",
     "wmar_rar_device_bytes", "wmar_rar_forward_position", "wmar_rar_generate", "wmar_vq_create", "wmar_vq_destroy", "wmar_vq_device_bytes",
     "wmar_vq_decode", "wmar_vq_encode", "wmar_mvq_create", "wmar_mvq_destroy", "wmar_mvq_device_bytes", "wmar_mvq_decode",
     "wmar_mvq_encode", "wmar_gumbel_key_build", "wmar_gumbel_sample", "wmar_gumbel_score", "wmar_rar_generate_gumbel",
@@ -128,6 +128,7 @@ def load():
     L.wmar_gpt_set_attention_phases.argtypes = [vp, i32, i32]
     L.wmar_gpt_profile_role.argtypes = [vp, i32, i64, i32, i32, vp, C.POINTER(f64)]
     L.wmar_gpt_get_timing.argtypes = [vp, C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]
+    L.wmar_gpt_plan_info.argtypes = [vp, i64, C.c_char_p, i64]
     L.wmar_rar_create.argtypes = [C.POINTER(RarConfig), C.POINTER(C.c_char_p), C.POINTER(vp), i32, vp, C.POINTER(vp)]
     L.wmar_rar_destroy.argtypes = [vp]
     L.wmar_rar_destroy.restype = None

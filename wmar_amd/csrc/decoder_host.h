@@ -94,8 +94,11 @@ inline int gemm_split(GemmArgs a, int* S_out, hipStream_t st, int force_S = 0) {
     return launch_gemm<1, NW, EPI_PACKED, false>(a, st);
 }
 
-// chunks of <= 16 k-blocks: one k_resid_stats workgroup (4 waves x 4 blocks) per chunk and row tile
-inline int stat_chunks(int KB) { return (KB + 15) / 16; }
+// chunks of <= WMAR_STAT_CHUNK k-blocks: one k_resid_stats workgroup (4 waves x up to 4 blocks) per chunk and row tile
+#ifndef WMAR_STAT_CHUNK
+#define WMAR_STAT_CHUNK 16
+#endif
+inline int stat_chunks(int KB) { const int n = (KB + WMAR_STAT_CHUNK - 1) / WMAR_STAT_CHUNK; return n <= STAT_CHUNKS_MAX ? n : (KB + 15) / 16; }
 
 
 // Device allocations of one engine (freed together).

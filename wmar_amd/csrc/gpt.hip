@@ -604,6 +604,28 @@ int wmar_gpt_profile_role(wmar_gpt* g, int32_t role, int64_t B, int32_t kv_len, 
     return WMAR_OK;
 }
 
+int wmar_gpt_plan_info(wmar_gpt* g, int64_t B, char* buf, int64_t buf_len) {
+    WMAR_REQUIRE(g && buf && buf_len > 0, "plan_info: null argument");
+    WMAR_REQUIRE(B >= 1 && B <= g->Bmax, "plan_info: batch outside 1..%d", g->Bmax);
+    StepIO io{g->past, (long long)g->Tmax + 1, 0, g->logits};
+    StepPlan p(g, B, io, nullptr);
+    const LayerW& w = g->layers[0];
+    char qkv[96], proj[96], fc1[96], fc2[96];
+    const int S_in = p.S_fc2 + (p.fc2_hi > 0 ? 1 : 0);
+    if (p.S_qx > 0 && p.MT == 2 && w.wqkvx_bx && !g->no_bx) snprintf(qkv, sizeof qkv, "k_qkvx_bx<%d> (bf16 pipe, %d K slices)", S_in, p.S_qx);
+    else if (p.S_qx > 0) snprintf(qkv, sizeof qkv, "k_qkvx<%d,%d> (fp32 MFMA, %d K slices)", p.MT, S_in, p.S_qx);
+    else snprintf(qkv, sizeof qkv, "k_gemm<EPI_PACKED> (fp32 MFMA, %d K slices) after k_resid_stats", p.S_qkv);
+    if (p.proj_bx) snprintf(proj, sizeof proj, "k_bx<1,%d> (bf16 pipe, %d K slices)", BX_PER, p.S_proj);
+    else snprintf(proj, sizeof proj, "k_gemm<EPI_PACKED> (fp32 MFMA, %d K slices)", p.S_proj);
+    if (p.MT == 2 && w.wfc1x16) snprintf(fc1, sizeof fc1, "k_fc1x (fp32 MFMA, 24-column tiles, whole K)");
+    else snprintf(fc1, sizeof fc1, "k_gemm<EPI_GELU,LN> (fp32 MFMA, whole K)");
+    snprintf(fc2, sizeof fc2, "k_gemm<EPI_PACKED> (fp32 MFMA, %d%s K slices)", p.S_fc2, p.fc2_hi > 0 ? "/+1" : "");
+    const int n = snprintf(buf, (size_t)buf_len, "qkv=%s;attn=k_attn_decode<%d,%d>;proj=%s;resid=k_resid_stats;fc1=%s;fc2=%s;head=k_gemm<EPI_LOGITS,LN> (fp32 MFMA)",
+                           qkv, g->hd, wmar_gpt::phase_waves(g->att_phase(g->Tmax / 2)), proj, fc1, fc2);
+    WMAR_REQUIRE(n > 0 && n < buf_len, "plan_info: buffer of %lld bytes too small", (long long)buf_len);
+    return WMAR_OK;
+}
+
 int wmar_gpt_set_attention_phases(wmar_gpt* g, int32_t one_wave_upto, int32_t two_waves_upto) {
     WMAR_REQUIRE(g && one_wave_upto >= 0 && two_waves_upto >= one_wave_upto, "set_attention_phases: bad thresholds");
     if (g->att_t1 != one_wave_upto || g->att_t2 != two_waves_upto) g->drop_graph();

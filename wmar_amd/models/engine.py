@@ -89,6 +89,12 @@ class GPTEngine:
                                                      _lib.stream_ptr(self.device), C.byref(out)))
         return out.value
 
+    def plan_info(self, B: int) -> Dict[str, str]:
+        """{role: kernel} of a decode step at batch B, as the engine selects them."""
+        buf = C.create_string_buffer(2048)
+        _lib.check(self._L.wmar_gpt_plan_info(self._h, int(B), buf, len(buf)))
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split(";"))
+
     def set_attention_phases(self, one_wave_upto: int, two_waves_upto: int):
         """Cache lengths up to which the decode attention runs 1 / 2 waves per (sequence, head) (4 beyond)."""
         _lib.check(self._L.wmar_gpt_set_attention_phases(self._h, int(one_wave_upto), int(two_waves_upto)))
