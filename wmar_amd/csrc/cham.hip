@@ -112,11 +112,12 @@ SkInfo sk_for(int NT, int KB, bool whole_groups) {
 
 template <int EPI>
 int launch_bgemm(const BGemmArgs& a, int MT, hipStream_t st) {
+    const dim3 grid((unsigned)a.sk.G);
     switch (MT) {
-        case 1: hipLaunchKernelGGL((k_bgemm<1, EPI>), dim3((unsigned)a.sk.G), dim3(256), 0, st, a); break;
-        case 2: hipLaunchKernelGGL((k_bgemm<2, EPI>), dim3((unsigned)a.sk.G), dim3(256), 0, st, a); break;
-        case 3: hipLaunchKernelGGL((k_bgemm<3, EPI>), dim3((unsigned)a.sk.G), dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL((k_bgemm<4, EPI>), dim3((unsigned)a.sk.G), dim3(256), 0, st, a); break;
+        case 1: hipLaunchKernelGGL((k_bgemm<1, EPI>), grid, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((k_bgemm<2, EPI>), grid, dim3(256), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((k_bgemm<3, EPI>), grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((k_bgemm<4, EPI>), grid, dim3(256), 0, st, a); break;
     }
     return launch_status("k_bgemm");
 }
@@ -310,6 +311,8 @@ int wmar_cham_create(const wmar_cham_config* cfg, const char* const* names, cons
     if (rc == WMAR_OK) {
         hipError_t er = hipMemsetAsync(g->x, 0, Mpad * D * 2, st);
         if (er == hipSuccess) er = hipMemsetAsync(g->y, 0, Mpad * D * 2, st);
+        if (er == hipSuccess) er = hipMemsetAsync(g->slabs, 0, (size_t)BG_MAXP * Mpad * D * 4, st);                       // padding rows are never written
+        if (er == hipSuccess) er = hipMemsetAsync(g->big_slabs, 0, (size_t)BG_MAXP * Mpad * (size_t)std::max(Nqkv, 2 * F) * 4, st);
         if (er == hipSuccess) er = hipMemsetAsync(g->hbuf, 0, Mpad * F * 2, st);
         if (er == hipSuccess) er = hipMemsetAsync(g->kcache, 0, kv * 2, st);
         if (er == hipSuccess) er = hipMemsetAsync(g->vcache, 0, kv * 2, st);

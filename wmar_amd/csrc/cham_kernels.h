@@ -140,8 +140,17 @@ __device__ __forceinline__ float cham_rstd(const double* __restrict__ ssq, int n
 // same number of weight bytes whatever N and K are.  When a workgroup leaves a group it writes its
 // partial sums as one "piece" of that group; consumers add the pieces of a group in piece order
 // (fixed, so results do not depend on timing).  sk_* below is the shared index arithmetic.
-constexpr int BG_KC = 8;         // k-blocks (of 16) per unit: 128 columns
-constexpr int BG_TG = 8;         // column tiles per group: 4 waves x 2 tiles share one staged activation chunk
+#ifndef WMAR_BG_KC
+#define WMAR_BG_KC 8
+#endif
+constexpr int BG_KC = WMAR_BG_KC;         // k-blocks (of 16) per unit
+#ifndef WMAR_BG_TG
+#define WMAR_BG_TG 4
+#endif
+// column tiles per group: the waves of a workgroup share one staged activation chunk.  4 (one tile per wave), not 8: a group's K range is
+// then cut into half as many pieces -- the fp32 partial-sum pieces of the four GEMMs of a block were 66 MB written and read again per
+// 422 MB of weights; measured 5.15 -> 4.67 ms per step on the 7B model (the activation chunk is read twice as often from L2 instead)
+constexpr int BG_TG = WMAR_BG_TG;
 constexpr int BG_MAXP = 16;      // pieces per group the slab buffers are sized for
 enum { BEPI_SLAB = 0, BEPI_LOGITS = 2 };
 
@@ -164,19 +173,22 @@ struct BGemmArgs {
     const double* ssq; int n_chunks; int K; float eps;   // 1/rms of the input rows (LOGITS)
 };
 
-template <int MT, int EPI>
-__global__ __launch_bounds__(256) void k_bgemm(BGemmArgs a) {
+// NWV waves per workgroup share the group's 8 column tiles: 4 waves x 2 tiles (one wave per SIMD) or 8 waves x 1 tile (two per SIMD:
+// while one waits for its weight loads the other multiplies).
+template <int MT, int EPI, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void k_bgemm(BGemmArgs a) {
+    constexpr int TPW = BG_TG / NWV, NTH = NWV * 64;
     __shared__ __attribute__((aligned(16))) uint4 xs[2 * BG_KC * MT * 64];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const SkInfo sk = a.sk;
     const long long u0 = (long long)blockIdx.x * sk.U / sk.G, u1 = ((long long)blockIdx.x + 1) * sk.U / sk.G;
     const int nu = (int)(u1 - u0);
-    constexpr int XPT = BG_KC * MT / 4;       // uint4 per thread per chunk (256 threads)
+    constexpr int XPT = BG_KC * MT / NWV;     // uint4 per thread per chunk
 
-    f32x16 acc[2][MT];
+    f32x16 acc[TPW][MT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -191,18 +203,18 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs a) {
     bool xact[XPT];
 #pragma unroll
     for (int u = 0; u < XPT; ++u) {
-        const int e = (threadIdx.x + u * 256) % (MT * 64);
+        const int e = (threadIdx.x + u * NTH) % (MT * 64);
         xact[u] = (e / 64) * 32 + (e & 31) < a.M;
     }
 
-    uint4 wA[2][BG_KC], wB[2][BG_KC], xr[XPT];
+    uint4 wA[TPW][BG_KC], wB[TPW][BG_KC], xr[XPT];
     // unit ui of this workgroup: group g, k-blocks [c*BG_KC, ...) clamped to KB-1 (clamped blocks are skipped by the MFMA loop)
 #define CH_LOADW(WB, UI)                                                                  \
     {                                                                                     \
         const long long uu = u0 + (UI);                                                   \
         const int g_ = (int)(uu / sk.C), c_ = (int)(uu % sk.C);                           \
-        _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                   \
-            const int nt_ = min(g_ * BG_TG + 2 * w + t, a.NT - 1);                        \
+        _Pragma("unroll") for (int t = 0; t < TPW; ++t) {                                 \
+            const int nt_ = min(g_ * BG_TG + TPW * w + t, a.NT - 1);                        \
             const uint4* wp_ = a.Wp + (long long)nt_ * a.KB * 64 + lane;                  \
             _Pragma("unroll") for (int u = 0; u < BG_KC; ++u)                             \
                 WB[t][u] = ld_nt_u4(wp_ + (long long)min(c_ * BG_KC + u, a.KB - 1) * 64); \
@@ -212,19 +224,19 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs a) {
     {                                                                                     \
         const int c_ = (int)((u0 + (UI)) % sk.C);                                         \
         _Pragma("unroll") for (int u = 0; u < XPT; ++u) {                                 \
-            const int e = threadIdx.x + u * 256;              /* element of [BG_KC][MT][64] */ \
+            const int e = threadIdx.x + u * NTH;              /* element of [BG_KC][MT][64] */ \
             const int kk = min(c_ * BG_KC + e / (MT * 64), a.KB - 1);                     \
-            xr[u] = make_uint4(0u, 0u, 0u, 0u);                                           \
-            if (xact[u]) xr[u] = a.Xp[(long long)kk * (MT * 64) + e % (MT * 64)];         \
+            xr[u] = a.Xp[(long long)kk * (MT * 64) + e % (MT * 64)];      /* unconditional: a load under a branch spoils hipcc's vmcnt counts */ \
+            if (!xact[u]) xr[u] = make_uint4(0u, 0u, 0u, 0u);                             \
         }                                                                                 \
     }
 #define CH_STOREX(BUF)                                                                    \
-    _Pragma("unroll") for (int u = 0; u < XPT; ++u) xs[(BUF) * (BG_KC * MT * 64) + threadIdx.x + u * 256] = xr[u];
+    _Pragma("unroll") for (int u = 0; u < XPT; ++u) xs[(BUF) * (BG_KC * MT * 64) + threadIdx.x + u * NTH] = xr[u];
 #define CH_MMA1(WB, BUF, U)                                                               \
     {                                                                                     \
         uint4 xv[MT];                                                                     \
         _Pragma("unroll") for (int i = 0; i < MT; ++i) xv[i] = xs[(BUF) * (BG_KC * MT * 64) + ((U) * MT + i) * 64 + lane]; \
-        _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                   \
+        _Pragma("unroll") for (int t = 0; t < TPW; ++t) {                                 \
             const bf16x8 wv = __builtin_bit_cast(bf16x8, WB[t][U]);                       \
             _Pragma("unroll") for (int i = 0; i < MT; ++i)                                \
                 acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, __builtin_bit_cast(bf16x8, xv[i]), acc[t][i], 0, 0, 0); \
@@ -247,13 +259,14 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs a) {
     auto flush = [&](int g) {
         const int hh = lane >> 5;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int nt = g * BG_TG + 2 * w + t;
+        for (int t = 0; t < TPW; ++t) {
+            const int nt = g * BG_TG + TPW * w + t;
             if (nt < a.NT) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     if (EPI == BEPI_SLAB) {
                         const int piece = (int)blockIdx.x - sk_first(sk, g);
+                        if (i * 32 + (lane & 31) >= a.M) continue;      // padding rows: their partial sums are never stored (the slab buffers start zeroed)
 #pragma unroll
                         for (int b = 0; b < 2; ++b) {
                             float* dst = a.slabs + (long long)piece * a.slab_stride + ((((long long)nt * 2 + b) * MT + i) * 64 + lane) * 8;
@@ -288,19 +301,22 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     CH_STOREX(0)
     __syncthreads();
+    // The prefetch of the next unit is UNCONDITIONAL (past the end it re-reads the last unit: L2 hits): under a run-time branch hipcc's
+    // s_waitcnt pass assumes the smaller outstanding count at the merge, every MFMA of unit u then also waits for unit u+1's loads
+    // and the register double buffer degenerates to one unit in flight.
     for (int ui = 0; ui < nu; ui += 2) {
-        if (ui + 1 < nu) { CH_LOADX(ui + 1) CH_LOADW(wB, ui + 1) }   // X first: waiting for it must not drain the weight loads
+        { const int un = min(ui + 1, nu - 1); CH_LOADX(un) CH_LOADW(wB, un) }   // X first: waiting for it must not drain the weight loads
         __builtin_amdgcn_sched_barrier(0);
         CH_UNIT(wA, 0, ui)
         __builtin_amdgcn_sched_barrier(0);
-        if (ui + 1 < nu) { CH_STOREX(1) }
+        CH_STOREX(1)
         __syncthreads();
         if (ui + 1 >= nu) break;
-        if (ui + 2 < nu) { CH_LOADX(ui + 2) CH_LOADW(wA, ui + 2) }
+        { const int un = min(ui + 2, nu - 1); CH_LOADX(un) CH_LOADW(wA, un) }
         __builtin_amdgcn_sched_barrier(0);
         CH_UNIT(wB, 1, ui + 1)
         __builtin_amdgcn_sched_barrier(0);
-        if (ui + 2 < nu) { CH_STOREX(0) }
+        CH_STOREX(0)
         __syncthreads();
     }
 #undef CH_LOADW

@@ -1560,16 +1560,19 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
         }                                                                                \
         m = mn;                                                                          \
     }
+    // The refills inside the loop are UNCONDITIONAL (rows past the cache clamp to row T-1: L1 hits): a load under a run-time branch
+    // makes hipcc's s_waitcnt pass take the smaller outstanding count of the two paths at the merge, i.e. every use of chunk c
+    // then waits for chunk c+1's loads as well and the double buffer degenerates to one chunk in flight.
+    if (!PF2 && w < nchunk) { WMAR_ATT_LOAD(kB, vB, w + NWA) }
+    __builtin_amdgcn_sched_barrier(0);
     for (int c = w; c < nchunk; c += 2 * NWA) {
-        if (!PF2 && c == w && c + NWA < nchunk) { WMAR_ATT_LOAD(kB, vB, c + NWA) }
-        __builtin_amdgcn_sched_barrier(0);
         WMAR_ATT_CHUNK(kA, vA, c)
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 2 * NWA < nchunk) { WMAR_ATT_LOAD(kA, vA, c + 2 * NWA) }
+        WMAR_ATT_LOAD(kA, vA, c + 2 * NWA)
         __builtin_amdgcn_sched_barrier(0);
         if (c + NWA < nchunk) { WMAR_ATT_CHUNK(kB, vB, c + NWA) }
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 3 * NWA < nchunk) { WMAR_ATT_LOAD(kB, vB, c + 3 * NWA) }
+        WMAR_ATT_LOAD(kB, vB, c + 3 * NWA)
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef WMAR_ATT_LOAD
