@@ -638,12 +638,13 @@ __global__ __launch_bounds__(NWA * 64) void k_cham_attn(ChamAttnArgs a) {
         }                                                                                 \
         mx = mn;                                                                          \
     }
+    // refills are unconditional (rows past the cache clamp to row T-1): see k_attn_decode
     for (int c = w; c < nchunk; c += 2 * NWA) {
-        if (c + NWA < nchunk) { CA_LOAD(kB, vB, c + NWA) }
+        CA_LOAD(kB, vB, c + NWA)
         __builtin_amdgcn_sched_barrier(0);
         CA_CHUNK(kA, vA, c)
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 2 * NWA < nchunk) { CA_LOAD(kA, vA, c + 2 * NWA) }
+        CA_LOAD(kA, vA, c + 2 * NWA)
         __builtin_amdgcn_sched_barrier(0);
         if (c + NWA < nchunk) { CA_CHUNK(kB, vB, c + NWA) }
         __builtin_amdgcn_sched_barrier(0);
