@@ -170,7 +170,8 @@ def main():
         dist.destroy_process_group()
     if chunk_id == 0 or world == 1:
         with open(os.path.join(args.outdir, "results.json"), "w") as f:
-            json.dump([{k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in r.items()} for r in recs], f)
+            # the code arrays live in <outdir>/codes/*.npy (30+ records per image x 256-1024 tokens would bloat the json)
+            json.dump([{k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in r.items() if k != "codes"} for r in recs], f)
         from wmar_amd.utils.analyzer import summarize
         with open(os.path.join(args.outdir, "summary.json"), "w") as f:      # TPR@1%FPR, mean l0 / PSNR per (method, transform, param)
             json.dump(summarize(recs), f, indent=1)

@@ -94,3 +94,20 @@ def test_dot_product_error_is_below_an_fp32_fma_chain():
         chain = (chain.astype(f) + x[:, k].astype(f) * w[:, k].astype(f)).astype(np.float32)     # fused multiply-add: one rounding
     e_bx, e_chain = np.abs(acc - exact).max(), np.abs(chain - exact).max()
     assert e_bx < e_chain, (e_bx, e_chain)
+
+
+def test_non_finite_and_overflowing_inputs_are_the_documented_exception():
+    """bx_split.h's stated limits, pinned: an infinite operand splits into (inf, NaN, NaN) -- inf - inf in the first remainder --
+    so a contraction that fp32 arithmetic would return as +-inf comes out NaN on the bf16 pipe; a finite value whose high piece
+    rounds up to infinity (|x| > 0x7f7f8000 = 3.3961e38) does the same; NaN stays NaN; everything else above 2^-100 is exact.
+    The opt-out for models with such activations is WMAR_NO_BX=1 / WMAR_CONV_NO_BX=1 (fp32-input MFMA kernels)."""
+    with np.errstate(invalid="ignore", over="ignore"):
+        h, m, l, _, _ = split3(np.array([np.inf, -np.inf, np.nan], dtype=np.float32))
+        assert np.isinf(h[0]) and np.isinf(h[1]) and np.isnan(h[2])
+        assert np.isnan(m).all() and np.isnan(l).all()
+        big = np.array([3.4e38, np.finfo(np.float32).max], dtype=np.float32)       # both round to +inf in bf16
+        hb, mb, lb, _, _ = split3(big)
+        assert np.isinf(hb).all() and not np.isfinite(mb).any()
+        ok = np.array([3.3895e38, -3.3895e38, 2.0 ** -99], dtype=np.float32)       # just inside the exact range
+        ho, mo, lo, _, _ = split3(ok)
+        assert np.array_equal(ho.astype(np.float64) + mo.astype(np.float64) + lo.astype(np.float64), ok.astype(np.float64))

@@ -138,3 +138,30 @@ def test_rar_1280_watermarked_loop_256_steps(pv, kat, rar, graph):
     assert np.array_equal(toks.cpu().numpy(), pv["rar_loop_tokens"].astype(np.int64))
     p = wm.detect(toks).cpu().numpy()
     assert np.allclose(np.log10(p), np.log10(pv["rar_loop_pvals"]), rtol=0, atol=1e-9)
+
+
+def test_fp32_mfma_opt_out_matches_the_bf16_pipe_on_the_reference_logits(pv):
+    """WMAR_NO_BX=1 (read at engine creation, production build): QKV and the output projection stay on the fp32-input MFMA kernels --
+    the opt-out for models whose activations may be non-finite (the bf16-piece split turns inf into NaN, bx_split.h).  Both paths
+    reproduce the reference's production-width logits."""
+    import os
+    from wmar_amd.models.engine import GPTEngine
+    gcfg = synth.GPTConfig(vocab_size=16384, block_size=256, n_layer=2, n_head=24, n_embd=1536)
+    sd = synth.synth_gpt_state(gcfg, seed=9, logit_scale=10.0)
+    seq = torch.from_numpy(pv["gpt_seq"].astype(np.int64)).cuda()
+    outs = {}
+    for tag, env in (("bx", None), ("fp32", "1")):
+        if env is None:
+            os.environ.pop("WMAR_NO_BX", None)
+        else:
+            os.environ["WMAR_NO_BX"] = env
+        try:
+            eng = GPTEngine(gcfg, sd, max_batch=64)
+            assert ("bf16 pipe" in eng.plan_info(64)["qkv"]) == (env is None)
+            outs[tag] = torch.stack([eng.decode_step(seq[:, t], t) for t in range(2)]).cpu().numpy()      # positions 0 and 1 = fixture rows 0 and 1
+        finally:
+            os.environ.pop("WMAR_NO_BX", None)
+    for tag in outs:
+        for t in range(2):
+            assert np.abs(outs[tag][t][:, ::64] - pv["gpt_logits"][t]).max() < 5e-4, tag
+    assert np.abs(outs["bx"] - outs["fp32"]).max() < 2e-4

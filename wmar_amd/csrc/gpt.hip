@@ -413,9 +413,11 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
             const char* e = getenv(names_s[i]);
             if (e) g->force_s[i] = atoi(e) > MAX_SLABS ? MAX_SLABS : atoi(e);
         }
-        g->no_bx = getenv("WMAR_NO_BX") != nullptr;
     }
 #endif
+    // WMAR_NO_BX=1 at engine creation (any build): QKV and the output projection stay on the fp32-input MFMA (k_qkvx / k_gemm).  The
+    // bf16-piece split turns an infinite operand into NaN where fp32 arithmetic gives +-inf (bx_split.h).
+    g->no_bx = getenv("WMAR_NO_BX") != nullptr;
     int rc = WMAR_OK;
     auto need = [&](const std::string& k) -> const float* {
         const float* p = tm.get(k);

@@ -907,11 +907,9 @@ bool in_attn_res(const wmar_vq_config& c, int res) {
     return false;
 }
 
-#ifdef WMAR_DEV_KNOBS
+// WMAR_CONV_NO_BX=1 (read once, any build): keep every convolution on the fp32-input MFMA.  The bf16-piece split turns an infinite
+// operand into NaN (inf - inf) where fp32 arithmetic gives +-inf (bx_split.h): a model with non-finite activations can opt out.
 static bool conv_no_bx() { static int v = -1; if (v < 0) v = getenv("WMAR_CONV_NO_BX") ? 1 : 0; return v != 0; }
-#else
-static constexpr bool conv_no_bx() { return false; }
-#endif
 #ifdef WMAR_DEV_KNOBS
 static bool vq_trace() { static int v = -1; if (v < 0) { const char* e = getenv("WMAR_VQ_TRACE"); v = e ? atoi(e) : 0; } return v != 0; }
 #else

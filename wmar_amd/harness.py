@@ -171,6 +171,8 @@ def gather_records(recs, eval_params, device, dst=0):
     import torch.distributed as dist
 
     rank, world = dist.get_rank(), dist.get_world_size()
+    unknown = set(eval_params["metric_names"]) - {"pvalue", "l0", "psnr"}
+    assert not unknown, f"gather_records carries pvalue / l0 / psnr only, not {sorted(unknown)}"
     combos = _combos(eval_params)
     index = {(t, str(p)): i for i, (t, p) in enumerate(combos)}
     n = len(recs)
@@ -186,6 +188,7 @@ def gather_records(recs, eval_params, device, dst=0):
         m = r["metrics"]
         bits = sum(1 << j for j, k in enumerate(("pvalue", "l0", "psnr")) if m.get(k) is not None)
         cond = r["conditioning"]
+        assert isinstance(cond, (int, float)) or hasattr(cond, "__int__"), f"conditioning {cond!r} must be numeric to be gathered (prompt tuples: pass their index)"
         rows[i] = torch.tensor([r["batch_idx"], float(cond), r["idx"], index[(r["transform"], str(r["param"]))],
                                 m["pvalue"] if bits & 1 else 0.0, m["l0"] if bits & 2 else 0.0, m["psnr"] if bits & 4 else 0.0,
                                 r["sample_seconds"], bits], dtype=torch.float64)
@@ -226,7 +229,9 @@ def generate_sharded(outdir, model, all_inputs, watermarker, eval_params, gen_pa
     world = dist.get_world_size() if dist.is_initialized() else 1
     seed_everything(seed, rank)
     recs = generate(outdir, model, all_inputs, watermarker, eval_params, gen_params, chunk_id=rank, num_chunks=world)
-    if world == 1:
+    if world == 1:        # the same record shape as the gathered one: only the requested metrics
+        for r in recs:
+            r["metrics"] = {k: v for k, v in r["metrics"].items() if k in eval_params["metric_names"]}
         return recs
     for r in recs:          # the method string is rank-independent; conditioning of a prompt tuple is its index
         if isinstance(r["conditioning"], tuple):

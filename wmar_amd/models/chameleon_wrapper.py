@@ -249,6 +249,9 @@ class ChameleonARMMWrapper(AutoregressiveMultimodalModelWrapper):
         (one engine forward + the text chain per token)."""
         v = self.vocab
         eng = self.model.engine
+        # the reference's interleaved mode serves one prompt per call (its split_token_sequence asserts batch 1): fail at entry, not
+        # after the whole generation
+        assert len(conditioning) == 1, f"sample_interleaved takes one prompt per call (got {len(conditioning)})"
         rows = []
         for _, prompt in conditioning:
             item = {"type": "text", "value": prompt} if isinstance(prompt, str) else {"type": "ids", "value": prompt}
