@@ -77,8 +77,14 @@ struct wmar_gpt {
     // Measured at batch 64 with the QKV projection arriving in 7 split-K pieces (round 2): one wave per (sequence, head) is the
     // fastest variant at every cache length up to 256 (the prologue that sums the pieces runs in wave 0 while the others
     // wait), so by default every step is phase 0.  wmar_gpt_set_attention_phases moves the thresholds.
+    // Small batches (fewer (sequence, head) pairs than two per CU) are the other regime: with the chip mostly idle, 2 waves per pair
+    // up to 128 cached rows and 4 beyond are 10-35 % faster (round 3, batch 1 / 8 / 16: scripts/perf_attn_nw.py).
     int att_t1 = 1 << 30, att_t2 = 1 << 30;
-    int att_phase(int kv) const { return kv <= att_t1 ? 0 : (kv <= att_t2 ? 1 : 2); }
+    bool att_user = false;         // thresholds set through wmar_gpt_set_attention_phases: used at every batch size
+    int att_phase(int kv, int64_t B) const {
+        if (!att_user && B * H < 512) return kv <= 128 ? 1 : 2;
+        return kv <= att_t1 ? 0 : (kv <= att_t2 ? 1 : 2);
+    }
     static int phase_waves(int ph) { return ph == 0 ? 1 : (ph == 1 ? 2 : 4); }
     int timing = 0;
     bool no_bx = false;           // dev knob WMAR_NO_BX: keep the fp32-MFMA k_qkvx
@@ -557,7 +563,7 @@ int wmar_gpt_decode_step(wmar_gpt* g, const int64_t* tok_dev, int64_t B, int32_t
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, g->pos_dev, (int)pos);
     StepIO io{(const long long*)tok_dev, 1, 0, logits_dev};
-    g->att_nw = wmar_gpt::phase_waves(g->att_phase(pos + 1));
+    g->att_nw = wmar_gpt::phase_waves(g->att_phase(pos + 1, B));
     return enqueue_step(g, B, io, st);
 }
 
@@ -569,7 +575,7 @@ int wmar_gpt_profile_role(wmar_gpt* g, int32_t role, int64_t B, int32_t kv_len, 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, g->pos_dev, (int)kv_len - 1);
     StepIO io{g->past, (long long)g->Tmax + 1, 0, g->logits};
-    g->att_nw = wmar_gpt::phase_waves(g->att_phase(kv_len));
+    g->att_nw = wmar_gpt::phase_waves(g->att_phase(kv_len, B));
     StepPlan p(g, B, io, st);
     // dev knob: WMAR_PROFILE_LAYERS=n cycles through the first n layers only (n = 1: weights stay in the memory-side cache)
     int ncycle = g->L;
@@ -623,7 +629,7 @@ int wmar_gpt_plan_info(wmar_gpt* g, int64_t B, char* buf, int64_t buf_len) {
     else snprintf(fc1, sizeof fc1, "k_gemm<EPI_GELU,LN> (fp32 MFMA, whole K)");
     snprintf(fc2, sizeof fc2, "k_gemm<EPI_PACKED> (fp32 MFMA, %d%s K slices)", p.S_fc2, p.fc2_hi > 0 ? "/+1" : "");
     const int n = snprintf(buf, (size_t)buf_len, "qkv=%s;attn=k_attn_decode<%d,%d>;proj=%s;resid=k_resid_stats;fc1=%s;fc2=%s;head=k_gemm<EPI_LOGITS,LN> (fp32 MFMA)",
-                           qkv, g->hd, wmar_gpt::phase_waves(g->att_phase(g->Tmax / 2)), proj, fc1, fc2);
+                           qkv, g->hd, wmar_gpt::phase_waves(g->att_phase(g->Tmax / 2, B)), proj, fc1, fc2);
     WMAR_REQUIRE(n > 0 && n < buf_len, "plan_info: buffer of %lld bytes too small", (long long)buf_len);
     return WMAR_OK;
 }
@@ -631,7 +637,7 @@ int wmar_gpt_plan_info(wmar_gpt* g, int64_t B, char* buf, int64_t buf_len) {
 int wmar_gpt_set_attention_phases(wmar_gpt* g, int32_t one_wave_upto, int32_t two_waves_upto) {
     WMAR_REQUIRE(g && one_wave_upto >= 0 && two_waves_upto >= one_wave_upto, "set_attention_phases: bad thresholds");
     if (g->att_t1 != one_wave_upto || g->att_t2 != two_waves_upto) g->drop_graph();
-    g->att_t1 = one_wave_upto; g->att_t2 = two_waves_upto;
+    g->att_t1 = one_wave_upto; g->att_t2 = two_waves_upto; g->att_user = true;
     return WMAR_OK;
 }
 
@@ -710,7 +716,7 @@ int wmar_gpt_generate(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_para
         memcpy(&key[8], &fd, 4); memcpy(&key[9], &ft, 4); memcpy(&key[11], &sp->top_p, 8);
         if (memcmp(key, g->graph_key, sizeof(key)) != 0) g->drop_graph();
         bool need[wmar_gpt::N_PHASE] = {false, false, false};
-        for (int n = 0; n < steps; ++n) need[g->att_phase(n + 1)] = true;
+        for (int n = 0; n < steps; ++n) need[g->att_phase(n + 1, B)] = true;
         bool have = true;
         for (int ph = 0; ph < wmar_gpt::N_PHASE; ++ph) have = have && (!need[ph] || g->exec[ph]);
         if (!have) {
@@ -728,7 +734,7 @@ int wmar_gpt_generate(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_para
             memcpy(g->graph_key, key, sizeof(key));
         }
         hipError_t e = hipSuccess;
-        for (int n = 0; n < steps && e == hipSuccess; ++n) e = hipGraphLaunch(g->exec[g->att_phase(n + 1)], st);
+        for (int n = 0; n < steps && e == hipSuccess; ++n) e = hipGraphLaunch(g->exec[g->att_phase(n + 1, B)], st);
         if (e == hipSuccess) e = hipEventRecord(g->ev1, st);   // also marks "replays finished" for drop_graph()
         if (e == hipSuccess) { g->pending = true; }
         if (e != hipSuccess) { set_error("graph replay failed: %s", hipGetErrorString(e)); return WMAR_EHIP; }
@@ -737,7 +743,7 @@ int wmar_gpt_generate(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_para
     } else {
         g->span_on = g->timing != 0;
         int rc = WMAR_OK;
-        for (int n = 0; n < steps && rc == WMAR_OK; ++n) rc = one_step(st, g->att_phase(n + 1));
+        for (int n = 0; n < steps && rc == WMAR_OK; ++n) rc = one_step(st, g->att_phase(n + 1, B));
         g->span_on = false;
         if (rc) return rc;
         if (g->timing) {
