@@ -130,7 +130,7 @@ __device__ __forceinline__ float cham_rstd(const double* __restrict__ ssq, int n
         for (int i = 0; i < 16; ++i)
             if (c0 + i < n_chunks) s += v[i];
     }
-    return rsqrtf((float)(s / (double)K) + eps);
+    return rsqrtf((float)(s * inv_count_f64((double)K)) + eps);
 }
 
 // ------------------------------------------------------------------------------- GEMM
@@ -363,7 +363,7 @@ static __global__ __launch_bounds__(256) void k_cham_swiglu(SwigluArgs a) {
     double tot = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) tot += red[i][lane & 31];
-    const float rstd = rsqrtf((float)(tot / (double)a.K) + a.eps);
+    const float rstd = rsqrtf((float)(tot * inv_count_f64((double)a.K)) + a.eps);
     float x1[8], x3[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { x1[j] = 0.f; x3[j] = 0.f; }
@@ -410,7 +410,7 @@ struct ChamResidArgs {
 
 template <bool EMBED>
 __global__ __launch_bounds__(256) void k_cham_resid(ChamResidArgs a) {
-    __shared__ double red[4][32];
+    __shared__ double red[4][64];
     const int c = blockIdx.x / a.MT, mt = blockIdx.x % a.MT;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int m = mt * 32 + (lane & 31), h = lane >> 5;
@@ -451,13 +451,14 @@ __global__ __launch_bounds__(256) void k_cham_resid(ChamResidArgs a) {
         }
         a.x[idx] = bf_pack8(r);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ss += (double)r[j] * r[j];
+        for (int j = 0; j < 8; ++j) ss += prod_f64(r[j], r[j]);       // never a v_fmac_f64 chain: common.h
     }
-    ss += __shfl_xor(ss, 32);
-    if (lane < 32) red[w][lane] = ss;
+    red[w][lane] = ss;            // all 64 lanes, no shuffle (decoder_kernels.h, k_qkvx_bx's keeper reduction)
     __syncthreads();
-    if (threadIdx.x < 32)
-        a.ssq[(long long)c * a.MT * 32 + mt * 32 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (threadIdx.x < 32) {
+        const int r = threadIdx.x;
+        a.ssq[(long long)c * a.MT * 32 + mt * 32 + r] = (red[0][r] + red[0][r + 32]) + (red[1][r] + red[1][r + 32]) + (red[2][r] + red[2][r + 32]) + (red[3][r] + red[3][r + 32]);
+    }
 }
 
 // ------------------------------------------------------------------------ decode attention
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(NWA * 64) void k_cham_attn(ChamAttnArgs a) {
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o);
-        const float rstd = rsqrtf((float)(ssum / (double)a.K) + a.eps);
+        const float rstd = rsqrtf((float)(ssum * inv_count_f64((double)a.K)) + a.eps);
         if (rsel == 0) {
 #pragma unroll
             for (int which = 0; which < 3; ++which)

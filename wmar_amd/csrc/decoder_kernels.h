@@ -57,7 +57,7 @@ static __global__ __launch_bounds__(64) void k_fold_bias(const float* __restrict
                                                   const float* __restrict__ beta, float* __restrict__ out, int K) {
     const int n = blockIdx.x, lane = threadIdx.x;
     double acc = 0.0;
-    for (int k = lane; k < K; k += 64) acc += (double)W[(long long)n * K + k] * (double)beta[k];
+    for (int k = lane; k < K; k += 64) acc += prod_f64(W[(long long)n * K + k], beta[k]);
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if (lane == 0) out[n] = (float)((bias ? (double)bias[n] : 0.0) + acc);
 }
@@ -97,7 +97,7 @@ struct ResidArgs {
 template <bool EMBED, int S>
 __global__ __launch_bounds__(256) void k_resid_stats(ResidArgs a) {
     constexpr int KPW = 4;  // k-blocks per wave (host guarantees chunk length <= 4*KPW)
-    __shared__ double red[4][32][2];
+    __shared__ double red[4][64][2];
     const int c = blockIdx.x / a.MT, mt = blockIdx.x % a.MT;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int kb0 = (int)((long long)c * a.KB / a.n_chunks), kb1 = (int)((long long)(c + 1) * a.KB / a.n_chunks);
@@ -155,15 +155,13 @@ __global__ __launch_bounds__(256) void k_resid_stats(ResidArgs a) {
         }
         a.x[((long long)kbs[i] * a.MT + mt) * 64 + lane] = r;
         s += (double)r.x + (double)r.y + (double)r.z + (double)r.w;
-        ss += (double)r.x * r.x + (double)r.y * r.y + (double)r.z * r.z + (double)r.w * r.w;
+        ss += sq4_f64(r);         // never a v_fmac_f64 chain: common.h
     }
-    s += __shfl_xor(s, 32);
-    ss += __shfl_xor(ss, 32);
-    if (lane < 32) { red[w][lane][0] = s; red[w][lane][1] = ss; }
+    red[w][lane][0] = s; red[w][lane][1] = ss;       // all 64 lanes, no shuffle: see k_qkvx_bx's keeper reduction
     __syncthreads();
     if (threadIdx.x < 32) {
         double ts = 0, tss = 0;
-        for (int i = 0; i < 4; ++i) { ts += red[i][threadIdx.x][0]; tss += red[i][threadIdx.x][1]; }
+        for (int i = 0; i < 4; ++i) { ts += red[i][threadIdx.x][0] + red[i][threadIdx.x + 32][0]; tss += red[i][threadIdx.x][1] + red[i][threadIdx.x + 32][1]; }
         const int Mpad = a.MT * 32;
         double* o = a.stats + ((long long)c * Mpad + mt * 32 + threadIdx.x) * 2;
         o[0] = ts; o[1] = tss;
@@ -205,10 +203,10 @@ __device__ __forceinline__ void ln_row_stats(const double* __restrict__ stats, i
         for (int i = 0; i < 16; ++i)
             if (c0 + i < n_chunks) { sm += v[i].x; sq += v[i].y; }
     }
-    const double invK = 1.0 / (double)K;
+    const double invK = inv_count_f64((double)K);
     const double mean = sm * invK;
     *mu = (float)mean;
-    *rstd = rsqrtf((float)(sq * invK - mean * mean) + 1e-5f);
+    *rstd = rsqrtf((float)var_f64(sq * invK, mean) + 1e-5f);
 }
 
 // ------------------------------------------------------------------------- skinny GEMM
@@ -760,7 +758,7 @@ struct QkvxArgs {
 template <int MTW, int S_IN>
 __global__ __launch_bounds__(512) void k_qkvx(QkvxArgs a) {
     __shared__ __attribute__((aligned(16))) float4 xs[2][QX_CK][MTW][64];
-    __shared__ double red[4][MTW][32][2];
+    __shared__ double red[4][MTW][64][2];      // every lane publishes its own partial sums (see the note at the keeper's reduction)
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
@@ -814,7 +812,7 @@ __global__ __launch_bounds__(512) void k_qkvx(QkvxArgs a) {
             if (keeper) {                                                                               \
                 a.x_out[((long long)SKB * MTW + i) * 64 + lane] = r;                                    \
                 sum[i] += (double)r.x + (double)r.y + (double)r.z + (double)r.w;                        \
-                sq[i] += (double)r.x * r.x + (double)r.y * r.y + (double)r.z * r.z + (double)r.w * r.w; \
+                sq[i] += sq4_f64(r);            /* never a v_fmac_f64 chain: common.h */                \
             }                                                                                           \
         }                                                                                               \
     }
@@ -846,16 +844,14 @@ __global__ __launch_bounds__(512) void k_qkvx(QkvxArgs a) {
         if (keeper) {
 #pragma unroll
             for (int i = 0; i < MTW; ++i) {
-                sum[i] += __shfl_xor(sum[i], 32);
-                sq[i] += __shfl_xor(sq[i], 32);
-                if (lane < 32) { red[sw][i][lane][0] = sum[i]; red[sw][i][lane][1] = sq[i]; }
+                red[sw][i][lane][0] = sum[i]; red[sw][i][lane][1] = sq[i];
             }
             __syncthreads();                               // the multiplying waves meet it after their stores
             const int t = threadIdx.x - 256;
             if (t < 32 * MTW) {
                 const int i = t >> 5, r = t & 31;
                 double ts = 0, tss = 0;
-                for (int ww = 0; ww < 4; ++ww) { ts += red[ww][i][r][0]; tss += red[ww][i][r][1]; }
+                for (int ww = 0; ww < 4; ++ww) { ts += red[ww][i][r][0] + red[ww][i][r + 32][0]; tss += red[ww][i][r][1] + red[ww][i][r + 32][1]; }
                 double* o = a.stats + ((long long)s * (MTW * 32) + i * 32 + r) * 2;
                 o[0] = ts; o[1] = tss;
             }
@@ -1011,7 +1007,7 @@ template <int S_IN>
 __global__ __launch_bounds__(512) void k_qkvx_bx(QkvxArgs a) {
     constexpr int MTW = 2;
     __shared__ __attribute__((aligned(16))) u32x4 xq[2][2][MTW][3][64];      // [buffer][step][row tile][piece][lane]
-    __shared__ double red[4][MTW][32][2];
+    __shared__ double red[4][MTW][64][2];      // every lane publishes its own partial sums (see the note at the keeper's reduction)
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
@@ -1069,7 +1065,7 @@ __global__ __launch_bounds__(512) void k_qkvx_bx(QkvxArgs a) {
             if (keeper) {                                                                               \
                 a.x_out[((long long)SKB * MTW + i) * 64 + lane] = r;                                    \
                 sum[i] += (double)r.x + (double)r.y + (double)r.z + (double)r.w;                        \
-                sq[i] += (double)r.x * r.x + (double)r.y * r.y + (double)r.z * r.z + (double)r.w * r.w; \
+                sq[i] += sq4_f64(r);            /* never a v_fmac_f64 chain: common.h */                \
             }                                                                                           \
         }                                                                                               \
     }
@@ -1097,18 +1093,18 @@ __global__ __launch_bounds__(512) void k_qkvx_bx(QkvxArgs a) {
 #undef WMAR_QX_ISSUE
 #undef WMAR_QX_FINISH
         if (keeper) {
+            // every lane stores its own (sum, sum of squares); the thread that owns row r adds lanes r and r + 32 of the four waves in a
+            // fixed order (the same additions the 64-bit __shfl_xor(., 32) of earlier rounds made)
 #pragma unroll
             for (int i = 0; i < MTW; ++i) {
-                sum[i] += __shfl_xor(sum[i], 32);
-                sq[i] += __shfl_xor(sq[i], 32);
-                if (lane < 32) { red[sw][i][lane][0] = sum[i]; red[sw][i][lane][1] = sq[i]; }
+                red[sw][i][lane][0] = sum[i]; red[sw][i][lane][1] = sq[i];
             }
             __syncthreads();                               // the multiplying waves meet it after their stores
             const int t = threadIdx.x - 256;
             if (t < 32 * MTW) {
                 const int i = t >> 5, r = t & 31;
                 double ts = 0, tss = 0;
-                for (int ww = 0; ww < 4; ++ww) { ts += red[ww][i][r][0]; tss += red[ww][i][r][1]; }
+                for (int ww = 0; ww < 4; ++ww) { ts += red[ww][i][r][0] + red[ww][i][r + 32][0]; tss += red[ww][i][r][1] + red[ww][i][r + 32][1]; }
                 double* o = a.stats + ((long long)s * (MTW * 32) + i * 32 + r) * 2;
                 o[0] = ts; o[1] = tss;
             }
@@ -1423,8 +1419,11 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
     const int Mpad = a.MT * 32;
     const int mt = b >> 5;
     double sm = 0, sq = 0;
+    // Every prologue load is UNCONDITIONAL per lane (indices clamped, unused values masked where they are summed): a load under a
+    // per-lane condition (`cond ? load : 0`) compiles to an exec-masked branch whose result is merged right behind it, i.e. one
+    // `s_waitcnt vmcnt(0)` per load -- a dozen serialized L2 round trips instead of one (round 3: the ISA showed exactly that).
     double2 st0 = make_double2(0.0, 0.0);
-    if (w == 0 && a.mode == 0 && lane < a.n_chunks) st0 = *(const double2*)(a.stats + ((long long)lane * Mpad + b) * 2);
+    if (w == 0) st0 = *(const double2*)(a.stats + ((long long)min(lane, a.n_chunks - 1) * Mpad + b) * 2);
     // The S split-K pieces of this head's 3 x hd columns are spread over the wave's RPI row groups (piece p is fetched by
     // group p % RPI), so that a lane holds at most PMAX pieces: all loads are still in flight together, without 3 x 8
     // float4 registers per lane (the kernel's occupancy is set by its registers).  The partial sums meet in a fixed
@@ -1435,36 +1434,34 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
     for (int which = 0; which < 3; ++which) {
         const int n = which * a.D + h * HD + sub * 4;          // first of this lane's 4 columns
         const long long idx = ((long long)(n >> 3) * a.MT + mt) * 64 + (b & 31) + 32 * ((n >> 2) & 1);
+        if (w == 0) {           // wave-uniform
 #pragma unroll
-        for (int pi = 0; pi < PMAX; ++pi) {
-            const int pc = rsel + pi * RPI;
-            sl[which][pi] = (w == 0 && pc < a.S) ? a.qkv_slabs[(long long)pc * a.slab_stride + idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (w == 0 && rsel == 0) {
-            cc[which] = a.mode == 0 ? *(const float4*)(a.c1 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int pi = 0; pi < PMAX; ++pi) {
+                const int pc = min(rsel + pi * RPI, a.S - 1);
+                sl[which][pi] = a.qkv_slabs[(long long)pc * a.slab_stride + idx];
+            }
+            cc[which] = *(const float4*)((a.mode == 0 ? a.c1 : a.bias) + n);     // (mode 1 has no c1: any valid address, value unused)
             bb[which] = *(const float4*)(a.bias + n);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (w < nchunk) { WMAR_ATT_LOAD(kA, vA, w) }
-    if (PF2 && w + NWA < nchunk) { WMAR_ATT_LOAD(kB, vB, w + NWA) }
+    WMAR_ATT_LOAD(kA, vA, w)                    // unconditional (clamped rows): see the refills below
+    if (PF2) { WMAR_ATT_LOAD(kB, vB, w + NWA) }
     __builtin_amdgcn_sched_barrier(0);
     if (w == 0) {
 #ifdef WMAR_ATT_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tr[1] = __builtin_amdgcn_s_memtime();
 #endif
-        sm = st0.x; sq = st0.y;
-        for (int c = lane + 64; a.mode == 0 && c < a.n_chunks; c += 64) {     // n_embd > 8192 only
-            const double2 v = *(const double2*)(a.stats + ((long long)c * Mpad + b) * 2);
-            sm += v.x; sq += v.y;
-        }
+        sm = lane < a.n_chunks ? st0.x : 0.0; sq = lane < a.n_chunks ? st0.y : 0.0;
+        // (n_chunks <= STAT_CHUNKS_MAX = 64: one chunk per lane; a loop over further chunks here would put a load in a loop and make
+        // hipcc wait for ALL outstanding loads, the first cache chunk included)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
         const double invK = a.invK;
         const double mean = sm * invK;
         const float mu = (float)mean;
-        const float rstd = rsqrtf((float)(sq * invK - mean * mean) + 1e-5f);
+        const float rstd = rsqrtf((float)var_f64(sq * invK, mean) + 1e-5f);
         float4 accs[3];
 #pragma unroll
         for (int which = 0; which < 3; ++which) {
@@ -1563,7 +1560,7 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
     // The refills inside the loop are UNCONDITIONAL (rows past the cache clamp to row T-1: L1 hits): a load under a run-time branch
     // makes hipcc's s_waitcnt pass take the smaller outstanding count of the two paths at the merge, i.e. every use of chunk c
     // then waits for chunk c+1's loads as well and the double buffer degenerates to one chunk in flight.
-    if (!PF2 && w < nchunk) { WMAR_ATT_LOAD(kB, vB, w + NWA) }
+    if (!PF2) { WMAR_ATT_LOAD(kB, vB, w + NWA) }
     __builtin_amdgcn_sched_barrier(0);
     for (int c = w; c < nchunk; c += 2 * NWA) {
         WMAR_ATT_CHUNK(kA, vA, c)

@@ -87,6 +87,8 @@ struct wmar_gpt {
     }
     static int phase_waves(int ph) { return ph == 0 ? 1 : (ph == 1 ? 2 : 4); }
     int timing = 0;
+    bool no_bx_qkv = false, no_bx_proj = false;   // dev knobs WMAR_NO_BX_QKV / WMAR_NO_BX_PROJ
+    unsigned long long* dbg_sums = nullptr; int dbg_slot = 0;   // dev only: see k_dbg_sum
     bool no_bx = false;           // dev knob WMAR_NO_BX: keep the fp32-MFMA k_qkvx
     int force_s[3] = {0, 0, 0};   // tuning knobs: WMAR_S_QKV / WMAR_S_PROJ / WMAR_S_FC2
     double step_ms = 0.0;
@@ -151,6 +153,18 @@ struct wmar_gpt {
 
 namespace {
 
+#ifdef WMAR_DEV_KNOBS
+// dev only (WMAR_DBG_SUMS=1): order-independent 64-bit checksum of a buffer after every launch of a step -- two runs of the same step
+// on the same state must agree slot by slot; the first slot that differs names the launch (scripts/stress_logits.py)
+__global__ void k_dbg_sum(const uint32_t* p, long long n, unsigned long long* slot) {
+    unsigned long long s = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        s += (unsigned long long)p[i] * (unsigned long long)(2 * i + 1);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(slot, s);
+}
+#endif
+
 struct StepIO {
     const long long* tok;  // row m's token: tok[m*stride + (use_pos ? pos : 0)]
     long long tok_stride;
@@ -204,8 +218,16 @@ struct StepPlan {
             if (S > KBD / QX_CK) S = KBD / QX_CK;
             if (S >= 1) S_qx = S;
         }
-        proj_bx = MT == 2 && g->yq && g->layers[0].wproj_bx && !g->no_bx && g->force_s[1] <= 0;
+        proj_bx = MT == 2 && g->yq && g->layers[0].wproj_bx && !g->no_bx && !g->no_bx_proj && g->force_s[1] <= 0;
         if (proj_bx) S_proj = D / BX_KSLICE;
+    }
+    void dbg(const void* p, long long bytes) {
+#ifdef WMAR_DEV_KNOBS
+        if (!g->dbg_sums || g->dbg_slot >= 4096) return;
+        hipLaunchKernelGGL(k_dbg_sum, dim3(512), dim3(256), 0, st, (const uint32_t*)p, bytes / 4, g->dbg_sums + g->dbg_slot++);
+#else
+        (void)p; (void)bytes;
+#endif
     }
     int split_for(int NT, int KB) const { return pick_split(MT % 2 == 0 ? NT * (MT / 2) : NT * MT, KB, 4); }
     GemmArgs base() const {
@@ -249,7 +271,7 @@ struct StepPlan {
         q.cap = ((q.NT / 4) * q.S + 7) / 8;
         g->span_begin(WMAR_T_QKV, st);
         int rc;
-        if (MT == 2 && w.wqkvx_bx && !g->no_bx) { q.Wp = w.wqkvx_bx; rc = launch_qkvx_bx(q, S_in, st); }   // 33..64 rows: bf16 matrix pipe
+        if (MT == 2 && w.wqkvx_bx && !g->no_bx && !g->no_bx_qkv) { q.Wp = w.wqkvx_bx; rc = launch_qkvx_bx(q, S_in, st); }   // 33..64 rows: bf16 matrix pipe
         else rc = launch_qkvx(q, MT, S_in, st);
         g->span_end(st);
         xcur = xout;
@@ -375,21 +397,38 @@ struct StepPlan {
 int enqueue_step(wmar_gpt* g, int64_t B, const StepIO& io, hipStream_t st) {
     StepPlan p(g, B, io, st);
     int rc;
+    const long long actb = p.act * 16, Mpad = p.MT * 32;
+#ifdef WMAR_DEV_KNOBS
+    if (g->dbg_sums) { g->dbg_slot = 0; if (hipMemsetAsync(g->dbg_sums, 0, 4096 * 8, st) != hipSuccess) return WMAR_EHIP; }
+#endif
     if ((rc = p.embed())) return rc;
-    for (int l = 0; l < g->L; ++l) {
+    p.dbg(p.xcur, actb); p.dbg(g->stats, p.nch * Mpad * 16);                                   // slots 0, 1
+    for (int l = 0; l < g->L; ++l) {                                                            // then 11 per layer:
         if (p.S_qx > 0) {
             if ((rc = p.qkvx(l, l > 0 ? g->layers[l - 1].bfc2 : nullptr))) return rc;
+            p.dbg(p.xcur, actb); p.dbg(g->stats_q, p.S_qx * Mpad * 16); p.dbg(g->qkv_slabs, p.S_qx * 3 * actb);   // +0 x', +1 stats, +2 QKV pieces
         } else {
             if (l > 0 && (rc = p.resid(g->layers[l - 1].bfc2, p.S_fc2, p.fc2_hi))) return rc;
             if ((rc = p.qkv(l))) return rc;
+            p.dbg(p.xcur, actb); p.dbg(g->stats, p.nch * Mpad * 16); p.dbg(g->qkv_slabs, 3 * actb);
         }
         if ((rc = p.attn(l))) return rc;
+        if (p.proj_bx) p.dbg(g->yq, (long long)p.D / 16 * 2 * 3 * 64 * 16); else p.dbg(g->y, actb);              // +3 attention output
+        {
+            const long long lstride = (long long)g->Bmax * g->H * g->Tmax * g->hd;
+            p.dbg(g->kcache + l * lstride, lstride * 4); p.dbg(g->vcache + l * lstride, lstride * 4);            // +4, +5 caches
+        }
         if ((rc = p.proj(l))) return rc;
+        p.dbg(g->slabs, p.S_proj * actb);                                                                        // +6 proj slabs
         if ((rc = p.resid(g->layers[l].bproj, p.S_proj))) return rc;
+        p.dbg(p.xcur, actb); p.dbg(g->stats, p.nch * Mpad * 16);                                                 // +7, +8
         if ((rc = p.fc1(l))) return rc;
+        p.dbg(g->hbuf, 4 * actb);                                                                                // +9 hidden
         if ((rc = p.fc2(l))) return rc;
+        p.dbg(g->slabs, p.S_fc2 * actb);                                                                         // +10 FC2 slabs (uniform part)
     }
     if ((rc = p.resid(g->layers[g->L - 1].bfc2, p.S_fc2, p.fc2_hi))) return rc;
+    p.dbg(p.xcur, actb); p.dbg(g->stats, p.nch * Mpad * 16);
     return p.head();
 }
 
@@ -424,6 +463,10 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
     // WMAR_NO_BX=1 at engine creation (any build): QKV and the output projection stay on the fp32-input MFMA (k_qkvx / k_gemm).  The
     // bf16-piece split turns an infinite operand into NaN where fp32 arithmetic gives +-inf (bx_split.h).
     g->no_bx = getenv("WMAR_NO_BX") != nullptr;
+#ifdef WMAR_DEV_KNOBS
+    if (getenv("WMAR_DBG_SUMS")) { if (hipMalloc(&g->dbg_sums, 4096 * 8) != hipSuccess) g->dbg_sums = nullptr; }
+    g->no_bx_qkv = getenv("WMAR_NO_BX_QKV") != nullptr; g->no_bx_proj = getenv("WMAR_NO_BX_PROJ") != nullptr;   // one role at a time (bisecting)
+#endif
     int rc = WMAR_OK;
     auto need = [&](const std::string& k) -> const float* {
         const float* p = tm.get(k);
@@ -633,6 +676,31 @@ int wmar_gpt_plan_info(wmar_gpt* g, int64_t B, char* buf, int64_t buf_len) {
     WMAR_REQUIRE(n > 0 && n < buf_len, "plan_info: buffer of %lld bytes too small", (long long)buf_len);
     return WMAR_OK;
 }
+
+#ifdef WMAR_DEV_KNOBS
+// dev only: the checksums of the last decode step (k_dbg_sum), n_out slots copied to the host
+int wmar_gpt_debug_sums(wmar_gpt* g, unsigned long long* out, int n_out, int* n_used) {
+    WMAR_REQUIRE(g && g->dbg_sums && out, "debug_sums: not enabled (WMAR_DBG_SUMS=1 at creation)");
+    WMAR_HIP_CHECK(hipDeviceSynchronize());
+    WMAR_HIP_CHECK(hipMemcpy(out, g->dbg_sums, (size_t)(n_out < 4096 ? n_out : 4096) * 8, hipMemcpyDeviceToHost));
+    if (n_used) *n_used = g->dbg_slot;
+    return WMAR_OK;
+}
+#endif
+
+#ifdef WMAR_DEV_KNOBS
+// dev only: row `pos` of every layer's K (which = 0) or V (1) cache -> out[L][Bmax][H][hd] on the host: the per-layer fingerprint of a
+// step that costs the step itself nothing (scripts/stress_kv.py)
+int wmar_gpt_debug_kv_row(wmar_gpt* g, int which, int pos, float* out) {
+    WMAR_REQUIRE(g && out && pos >= 0 && pos < g->Tmax, "debug_kv_row: bad argument");
+    WMAR_HIP_CHECK(hipDeviceSynchronize());
+    const float* src = (which ? g->vcache : g->kcache) + (long long)pos * g->hd;
+    WMAR_HIP_CHECK(hipMemcpy2D(out, (size_t)g->hd * 4, src, (size_t)g->Tmax * g->hd * 4, (size_t)g->hd * 4,
+                               (size_t)g->L * g->Bmax * g->H, hipMemcpyDeviceToHost));
+    return WMAR_OK;
+}
+#endif
+
 
 int wmar_gpt_set_attention_phases(wmar_gpt* g, int32_t one_wave_upto, int32_t two_waves_upto) {
     WMAR_REQUIRE(g && one_wave_upto >= 0 && two_waves_upto >= one_wave_upto, "set_attention_phases: bad thresholds");

@@ -43,7 +43,7 @@ struct RarEmbedArgs {
 
 static __global__ __launch_bounds__(256) void k_rar_embed(RarEmbedArgs a) {
     constexpr int KPW = 4;
-    __shared__ double red[4][32][2];
+    __shared__ double red[4][64][2];
     const int c = blockIdx.x / a.MT, mt = blockIdx.x % a.MT;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int kb0 = (int)((unsigned)c * (unsigned)a.KB / (unsigned)a.n_chunks);
@@ -76,20 +76,18 @@ static __global__ __launch_bounds__(256) void k_rar_embed(RarEmbedArgs a) {
         }
         a.x[idx] = r;
         s += (double)r.x + (double)r.y + (double)r.z + (double)r.w;
-        ss += (double)r.x * r.x + (double)r.y * r.y + (double)r.z * r.z + (double)r.w * r.w;
+        ss += sq4_f64(r);         // never a v_fmac_f64 chain: common.h
         float4 ce = *(const float4*)(crow + k), te = *(const float4*)(srow + k);
         float cv[4] = {ce.x + te.x, ce.y + te.y, ce.z + te.z, ce.w + te.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) cv[j] = cv[j] / (1.0f + expf(-cv[j]));   // SiLU
         if (mt < a.MTsc) a.sc[((long long)kb * a.MTsc + mt) * 64 + lane] = make_float4(cv[0], cv[1], cv[2], cv[3]);
     }
-    s += __shfl_xor(s, 32);
-    ss += __shfl_xor(ss, 32);
-    if (lane < 32) { red[w][lane][0] = s; red[w][lane][1] = ss; }
+    red[w][lane][0] = s; red[w][lane][1] = ss;       // all 64 lanes, no shuffle (decoder_kernels.h, k_qkvx_bx's keeper reduction)
     __syncthreads();
     if (threadIdx.x < 32) {
         double ts = 0, tss = 0;
-        for (int i = 0; i < 4; ++i) { ts += red[i][threadIdx.x][0]; tss += red[i][threadIdx.x][1]; }
+        for (int i = 0; i < 4; ++i) { ts += red[i][threadIdx.x][0] + red[i][threadIdx.x + 32][0]; tss += red[i][threadIdx.x][1] + red[i][threadIdx.x + 32][1]; }
         double* o = a.stats + ((long long)c * a.MT * 32 + mt * 32 + threadIdx.x) * 2;
         o[0] = ts; o[1] = tss;
     }
@@ -148,10 +146,10 @@ static __global__ __launch_bounds__(256) void k_modulate(ModArgs a) {
             for (int i = 0; i < 16; ++i)
                 if (c0 + i < a.n_chunks) { sm += st[i].x; sq += st[i].y; }
         }
-        const double invK = 1.0 / (double)a.K;
+        const double invK = inv_count_f64((double)a.K);
         const double mean = sm * invK;
         mu = (float)mean;
-        rstd = rsqrtf((float)(sq * invK - mean * mean) + 1e-6f);
+        rstd = rsqrtf((float)var_f64(sq * invK, mean) + 1e-6f);
     }
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
@@ -190,7 +188,7 @@ struct ResidModArgs {
 // launch is bound by each workgroup's read of its slab chunk from the other XCDs' L2 / the memory-side cache), 4 beyond 2048 features.
 template <int S, int KPW>
 __global__ __launch_bounds__(256) void k_resid_mod(ResidModArgs a) {
-    __shared__ double red[4][32][2];
+    __shared__ double red[4][64][2];
     __shared__ double grp[8][32][2];
     __shared__ float s_mu[32], s_rs[32];
     const ResidArgs& r = a.r;
@@ -241,16 +239,14 @@ __global__ __launch_bounds__(256) void k_resid_mod(ResidModArgs a) {
         rv[i] = x;
         r.x[((long long)kbs[i] * r.MT + mt) * 64 + lane] = x;
         s += (double)x.x + (double)x.y + (double)x.z + (double)x.w;
-        ss += (double)x.x * x.x + (double)x.y * x.y + (double)x.z * x.z + (double)x.w * x.w;
+        ss += sq4_f64(x);         // never a v_fmac_f64 chain: common.h
     }
-    s += __shfl_xor(s, 32);
-    ss += __shfl_xor(ss, 32);
-    if (lane < 32) { red[w][lane][0] = s; red[w][lane][1] = ss; }
+    red[w][lane][0] = s; red[w][lane][1] = ss;       // all 64 lanes, no shuffle (decoder_kernels.h, k_qkvx_bx's keeper reduction)
     __syncthreads();
     constexpr unsigned long long POISON = ~0ull;
     if (w == 0 && lane < 32) {
         double ts = 0, tss = 0;
-        for (int i = 0; i < 4; ++i) { ts += red[i][lane][0]; tss += red[i][lane][1]; }
+        for (int i = 0; i < 4; ++i) { ts += red[i][lane][0] + red[i][lane + 32][0]; tss += red[i][lane][1] + red[i][lane + 32][1]; }
         unsigned long long* o = a.part + ((long long)c * Mpad + mt * 32 + lane) * 2;
         __hip_atomic_store(o, (unsigned long long)__double_as_longlong(ts), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(o + 1, (unsigned long long)__double_as_longlong(tss), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -288,10 +284,10 @@ __global__ __launch_bounds__(256) void k_resid_mod(ResidModArgs a) {
     if (threadIdx.x < 32) {
         double sm = 0, sq = 0;
         for (int q = 0; q < 8; ++q) { sm += grp[q][threadIdx.x][0]; sq += grp[q][threadIdx.x][1]; }
-        const double invK = 1.0 / (double)r.K;
+        const double invK = inv_count_f64((double)r.K);
         const double mean = sm * invK;
         s_mu[threadIdx.x] = (float)mean;
-        s_rs[threadIdx.x] = rsqrtf((float)(sq * invK - mean * mean) + 1e-6f);
+        s_rs[threadIdx.x] = rsqrtf((float)var_f64(sq * invK, mean) + 1e-6f);
     }
     __syncthreads();
     const float mu = s_mu[lane & 31], rstd = s_rs[lane & 31];

@@ -128,6 +128,15 @@ __device__ __forceinline__ float4 conv_gn(const ConvArgs& a, float4 v, int b, in
     return make_float4(r[0], r[1], r[2], r[3]);
 }
 
+// the same normalisation with the parameters already in registers (k_conv_bx requests them a whole round ahead)
+__device__ __forceinline__ float4 conv_gn_apply(float4 v, const float4 g, const float4 bt, const float2 m, int swish) {
+    float r[4] = {(v.x - m.x) * m.y * g.x + bt.x, (v.y - m.x) * m.y * g.y + bt.y, (v.z - m.x) * m.y * g.z + bt.z, (v.w - m.x) * m.y * g.w + bt.w};
+    if (swish)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = r[i] / (1.0f + __expf(-r[i]));
+    return make_float4(r[0], r[1], r[2], r[3]);
+}
+
 // Epilogue of both conv kernels: bias (+ residual), NHWC store, per-tile GroupNorm partial sums of the output.
 __device__ __forceinline__ void conv_store(const ConvArgs& a, const f32x16 (&acc)[2], int b, int ct, int ty, int tx, int lane) {
     const int j = lane & 31, half = lane >> 5;
@@ -153,7 +162,7 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, const f32x16 (&acc
             *(float4*)(a.out + pix * a.Cout_s + co) = o;
             if (a.st_part) {
                 gs[g] += (double)o.x + (double)o.y + (double)o.z + (double)o.w;
-                gss[g] += (double)o.x * o.x + (double)o.y * o.y + (double)o.z * o.z + (double)o.w * o.w;
+                gss[g] += sq4_f64(o);      // never a v_fmac_f64 chain: common.h
             }
         }
     }
@@ -386,7 +395,9 @@ __global__ __launch_bounds__(COT * 64) void k_conv_bx(ConvArgs a) {
 #define WMAR_CONVBX_STAGE(DST, C0)                                                                              \
     _Pragma("unroll") for (int i = 0; i < NPT; ++i)                                                             \
         if (loff[i] >= 0) {                                                                                     \
-            if (a.gn_mr && goff[i] >= 0) pr[i] = conv_gn(a, pr[i], b, (C0) + (threadIdx.x + i * COT * 64) % 8 * 4); \
+            if (goff[i] < 0) pr[i] = make_float4(0.f, 0.f, 0.f, 0.f);          /* zero padding (the load itself was unconditional) */ \
+            else if (gn_fast) pr[i] = conv_gn_apply(pr[i], gnG, gnB, gnM, a.gn_swish);                          \
+            else if (a.gn_mr) pr[i] = conv_gn(a, pr[i], b, (C0) + cthr);                                        \
             unsigned h0, m0, l0, h1, m1, l1;                                                                    \
             bx_split2(pr[i].x, pr[i].y, h0, m0, l0);                                                            \
             bx_split2(pr[i].z, pr[i].w, h1, m1, l1);                                                            \
@@ -407,8 +418,18 @@ __global__ __launch_bounds__(COT * 64) void k_conv_bx(ConvArgs a) {
       const unsigned char* p1_ = p0_ + 4 * PW * CONV_PSTRIDE_BX;                                                 \
       xr[SLOT][0] = *(const u32x4*)p0_; xr[SLOT][1] = *(const u32x4*)(p0_ + 64); xr[SLOT][2] = *(const u32x4*)(p0_ + 128); \
       xr[SLOT][3] = *(const u32x4*)p1_; xr[SLOT][4] = *(const u32x4*)(p1_ + 64); xr[SLOT][5] = *(const u32x4*)(p1_ + 128); }
+    // GroupNorm parameters of this thread's four channels (gamma, beta, the group's mean / rstd): they depend on the round only, so
+    // they are requested a whole round ahead, in front of the patch -- inside the staging they were a dependent L2 round trip per
+    // round with every wave of the workgroup waiting (and the wait drained the weight ring as well)
+    const int cthr = (threadIdx.x % 8) * 4;
+    const bool gn_fast = a.gn_mr && a.gn_cpg >= 4 && (a.gn_cpg & 3) == 0;
+    float4 gnG = make_float4(1.f, 1.f, 1.f, 1.f), gnB = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 gnM = make_float2(0.f, 1.f);
+#define WMAR_CONVBX_GN(C0)                                                                                      \
+    if (gn_fast) { const int c_ = (C0) + cthr; gnG = *(const float4*)(a.gn_g + c_); gnB = *(const float4*)(a.gn_b + c_); gnM = a.gn_mr[b * 32 + c_ / a.gn_cpg]; }
+    WMAR_CONVBX_GN(0)
 #pragma unroll
-    for (int i = 0; i < NPT; ++i) pr[i] = goff[i] >= 0 ? *(const float4*)(inb + goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < NPT; ++i) pr[i] = *(const float4*)(inb + (goff[i] >= 0 ? goff[i] : 0));
     WMAR_CONVBX_LOADW(0, 0, 0)
     if (WR > 2) { WMAR_CONVBX_LOADW(1, 0, 1) }
     WMAR_CONVBX_STAGE(patchb, 0)
@@ -417,11 +438,13 @@ __global__ __launch_bounds__(COT * 64) void k_conv_bx(ConvArgs a) {
     const int rounds = a.Cin / CONV_CCH;
     for (int r = 0; r < rounds; ++r) {
         const bool more = r + 1 < rounds;
-        if (more) {
+        // the next round's patch and (at the end of this round) its first weights are requested UNCONDITIONALLY -- in the last round a
+        // harmless re-read of the same round: a prefetch under a run-time branch makes hipcc's wait-count pass assume the smaller
+        // outstanding count at the merge, and the last steps of every round then wait for the next round's loads as well
+        const int rn = more ? r + 1 : r;
+        WMAR_CONVBX_GN(rn * CONV_CCH)
 #pragma unroll
-            for (int i = 0; i < NPT; ++i)
-                pr[i] = goff[i] >= 0 ? *(const float4*)(inb + goff[i] + (r + 1) * CONV_CCH) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int i = 0; i < NPT; ++i) pr[i] = *(const float4*)(inb + (goff[i] >= 0 ? goff[i] : 0) + rn * CONV_CCH);   // unconditional; padding is zeroed when staged
         const unsigned char* cur = patchb + buf * psz;
         WMAR_CONVBX_LOADX(0, cur, 0)
         __builtin_amdgcn_sched_barrier(0);
@@ -429,7 +452,7 @@ __global__ __launch_bounds__(COT * 64) void k_conv_bx(ConvArgs a) {
         for (int it = 0; it < NIT; ++it) {
             // weights of step it + WR - 1 (the next round's first steps at the end of this one), patch operands of step it + 1
             if (it + WR - 1 < NIT) { WMAR_CONVBX_LOADW((it + WR - 1) % WR, r, it + WR - 1) }
-            else if (more) { WMAR_CONVBX_LOADW((it + WR - 1) % WR, r + 1, it + WR - 1 - NIT) }
+            else { WMAR_CONVBX_LOADW((it + WR - 1) % WR, rn, it + WR - 1 - NIT) }
             if (it + 1 < NIT) { WMAR_CONVBX_LOADX((it + 1) % XR, cur, it + 1) }
             __builtin_amdgcn_sched_barrier(0);
             const u32x4 wh = wr[it % WR][0], wm = wr[it % WR][1], wl = wr[it % WR][2];
@@ -451,6 +474,7 @@ __global__ __launch_bounds__(COT * 64) void k_conv_bx(ConvArgs a) {
         __syncthreads();
         buf ^= 1;
     }
+#undef WMAR_CONVBX_GN
 #undef WMAR_CONVBX_STAGE
 #undef WMAR_CONVBX_MFMA
 #undef WMAR_CONVBX_LOADW
@@ -482,10 +506,10 @@ __global__ __launch_bounds__(256) void k_gn_partial(GnArgs a) {
     if (prow < pstep)
         for (int p = p0 + prow; p < p1; p += pstep) {
             float4 v = *(const float4*)(xb + (long long)p * a.C + col * 4);
-            s[0] += v.x; ss[0] += (double)v.x * v.x;
-            s[1] += v.y; ss[1] += (double)v.y * v.y;
-            s[2] += v.z; ss[2] += (double)v.z * v.z;
-            s[3] += v.w; ss[3] += (double)v.w * v.w;
+            s[0] += v.x; ss[0] += prod_f64(v.x, v.x);       // never a v_fmac_f64 chain: common.h
+            s[1] += v.y; ss[1] += prod_f64(v.y, v.y);
+            s[2] += v.z; ss[2] += prod_f64(v.z, v.z);
+            s[3] += v.w; ss[3] += prod_f64(v.w, v.w);
         }
     // fold the 4 channels of this thread into their groups, then reduce threads in fixed order
     __shared__ double acc[32][2];
@@ -520,9 +544,10 @@ __global__ void k_gn_finalize(GnArgs a, float2* mr) {
         ts += p[0]; tss += p[1];
     }
     const double n = (double)a.HW * (a.C / 32);
-    const double mean = ts / n;
-    const double var = tss / n - mean * mean;
-    mr[b * 32 + g] = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-6)));
+    const double rn = inv_count_f64(n);          // no fp64 division / sqrt expansions (chains of fused multiply-adds): common.h
+    const double mean = ts * rn;
+    const double var = var_f64(tss * rn, mean);
+    mr[b * 32 + g] = make_float2((float)mean, (float)rsqrt_f64(var + 1e-6));
 }
 
 // (mean, rstd) from the per-tile partial sums a conv epilogue left behind: 8 thread groups add every 8th tile in order, then
@@ -538,9 +563,10 @@ __global__ __launch_bounds__(256) void k_gn_finalize_tiles(const double* part, i
     if (threadIdx.x < 32) {
         ts = 0; tss = 0;
         for (int i = 0; i < 8; ++i) { ts += red[i][g][0]; tss += red[i][g][1]; }
-        const double mean = ts / count;
-        const double var = tss / count - mean * mean;
-        mr[b * 32 + g] = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-6)));
+        const double rn = inv_count_f64(count);  // no fp64 division / sqrt expansions (chains of fused multiply-adds): common.h
+        const double mean = ts * rn;
+        const double var = var_f64(tss * rn, mean);
+        mr[b * 32 + g] = make_float2((float)mean, (float)rsqrt_f64(var + 1e-6));
     }
 }
 
