@@ -1,7 +1,7 @@
 """Dev tool: time the full-size Taming GPT decode loop (random weights)."""
 import os, sys, time
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.environ.get("WMAR_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from wmar_amd.utils import synth
 from wmar_amd.models.engine import GPTEngine
