@@ -116,7 +116,10 @@ __device__ __forceinline__ int scan_hist(const unsigned long long* hist, unsigne
 // EPT > 0: the whole row lives in registers (EPT values per thread, V <= EPT*1024) and every pass
 // after the first runs out of registers -- with the row in memory each of the ~13 passes is a chain
 // of dependent L2 round trips (measured 75 us/step).  EPT == 0: generic path through `scratch`.
-template <int EPT>
+// PLAIN: no gather table, no guidance streams, no allow-list, no logits trace (the Taming / RAR-without-guidance call): every load of
+// the first pass is then unconditional (clamped index) and issued before the first use -- under the per-element conditions of the
+// general path hipcc waits for each load on its own (`s_waitcnt vmcnt(0)` behind every one: ~48 serialized L2 round trips per row).
+template <int EPT, bool PLAIN = false>
 __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
     __shared__ unsigned long long hist[256];
     __shared__ unsigned long long red[SAMP_WAVES];
@@ -165,10 +168,39 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
 #pragma unroll
         for (int i = 0; i < QN; ++i) {
             const long long v = tid + (long long)i * SAMP_THREADS;
-            qpre[i] = v < V ? q[WMAR_SRC(v)] : 1.f;
+            if (PLAIN) qpre[i] = q[v < V ? v : V - 1];
+            else qpre[i] = v < V ? q[WMAR_SRC(v)] : 1.f;
         }
     }
-    if (EPT > 0) {
+    if (EPT > 0 && PLAIN) {
+        constexpr int CH = EPT > 8 ? 8 : (EPT > 0 ? EPT : 1);        // 8 logits + 8 key words in flight beside the 16 noise values: no spills at 128 VGPRs
+        const uint32_t* gp = grow ? grow : reinterpret_cast<const uint32_t*>(lg);     // no key row: any valid words, never used
+#pragma unroll
+        for (int c0 = 0; c0 < (EPT > 0 ? EPT : 1); c0 += CH) {
+            float lv[CH];
+            uint32_t gw[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const long long v = tid + (long long)(c0 + j) * SAMP_THREADS;
+                const long long vv = v < V ? v : V - 1;
+                lv[j] = lg[vv];
+                gw[j] = gp[vv >> 5];
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int i = c0 + j;
+                const long long v = tid + (long long)i * SAMP_THREADS;
+                if (v < V) {
+                    float xv = lv[j];
+                    if (grow && ((gw[j] >> (v & 31)) & 1u)) xv = xv + delta;
+                    xv = xv / T;
+                    xr[i] = xv;
+                    if (a.scratch) x[v] = xv;
+                    kmax = max(kmax, wmar_f32_key(xv));
+                }
+            }
+        }
+    } else if (EPT > 0) {
         // chunks of 16 values per thread: all loads of a chunk are issued before its arithmetic (one round trip per chunk),
         // without holding a second copy of a 64-value row in registers
         constexpr int CH = EPT > 16 ? 16 : (EPT > 0 ? EPT : 1);
@@ -521,7 +553,9 @@ __global__ __launch_bounds__(256) void k_detect(DetArgs a) {
 
 // Launch helper shared with the generation graph (gpt.hip).
 int launch_sample_fused(const SampArgs& a, hipStream_t st) {
-    if (a.V <= 16ll * SAMP_THREADS) hipLaunchKernelGGL(k_sample_fused<16>, dim3((unsigned)a.B), dim3(SAMP_THREADS), 0, st, a);
+    const bool plain = !a.gather && !a.logits_uncond && !a.logits_img && !a.allow && !a.trace;
+    if (a.V <= 16ll * SAMP_THREADS && plain) hipLaunchKernelGGL((k_sample_fused<16, true>), dim3((unsigned)a.B), dim3(SAMP_THREADS), 0, st, a);
+    else if (a.V <= 16ll * SAMP_THREADS) hipLaunchKernelGGL(k_sample_fused<16>, dim3((unsigned)a.B), dim3(SAMP_THREADS), 0, st, a);
     else if (a.V <= 64ll * SAMP_THREADS) hipLaunchKernelGGL(k_sample_fused<64>, dim3((unsigned)a.B), dim3(SAMP_THREADS), 0, st, a);
     else hipLaunchKernelGGL(k_sample_fused<0>, dim3((unsigned)a.B), dim3(SAMP_THREADS), 0, st, a);
     return launch_status("k_sample_fused");
