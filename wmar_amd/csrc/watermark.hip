@@ -269,26 +269,34 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
                 // The top byte (sign + 7 exponent bits) takes a handful of values: per-lane LDS
                 // atomics on the same bucket serialise, so each wave first counts its lanes per
                 // distinct digit (ballot) and issues ONE add per digit.
-                for (int i_ = 0; i_ < (int)((V + SAMP_THREADS - 1) / SAMP_THREADS); ++i_) {
-                    const long long v = tid + (long long)i_ * SAMP_THREADS;
-                    bool active = v < V;
-                    float xv = 0.f;
-                    if (EPT > 0) {
+#define WMAR_TOPBYTE(V_, XV_)                                                                         \
+                {                                                                                         \
+                    const bool active = (V_) < V;                                                         \
+                    const uint32_t d = active ? (wmar_f32_key(XV_) >> 24) : 0u;                           \
+                    unsigned long long todo = __ballot(active);                                           \
+                    while (todo) {                                                                        \
+                        const int leader = __ffsll((long long)todo) - 1;                                  \
+                        const uint32_t dl = (uint32_t)__shfl((int)d, leader);                             \
+                        const unsigned long long same = __ballot(active && d == dl);                      \
+                        if ((tid & 63) == leader) atomicAdd(&hist[dl], (unsigned long long)__popcll(same)); \
+                        todo &= ~same;                                                                    \
+                    }                                                                                     \
+                }
+                if (EPT > 0) {       // (direct register access: selecting xr[i_] by a run-time i_ was an EPT^2 chain of v_cndmask)
 #pragma unroll
-                        for (int j = 0; j < (EPT > 0 ? EPT : 1); ++j) if (j == i_) xv = xr[j];
-                    } else if (active) {
-                        xv = x[v];
+                    for (int i_ = 0; i_ < (EPT > 0 ? EPT : 1); ++i_) {
+                        if ((long long)i_ * SAMP_THREADS >= V) break;            // block-uniform
+                        const long long v = tid + (long long)i_ * SAMP_THREADS;
+                        WMAR_TOPBYTE(v, xr[i_])
                     }
-                    const uint32_t d = active ? (wmar_f32_key(xv) >> 24) : 0u;
-                    unsigned long long todo = __ballot(active);
-                    while (todo) {
-                        const int leader = __ffsll((long long)todo) - 1;
-                        const uint32_t dl = (uint32_t)__shfl((int)d, leader);
-                        const unsigned long long same = __ballot(active && d == dl);
-                        if ((tid & 63) == leader) atomicAdd(&hist[dl], (unsigned long long)__popcll(same));
-                        todo &= ~same;
+                } else {
+                    for (long long v0 = 0; v0 < V; v0 += SAMP_THREADS) {
+                        const long long v = v0 + tid;
+                        const float xv = v < V ? x[v] : 0.f;
+                        WMAR_TOPBYTE(v, xv)
                     }
                 }
+#undef WMAR_TOPBYTE
             } else {
                 WMAR_FOR_ROW({
                     const uint32_t k = wmar_f32_key(xv);
