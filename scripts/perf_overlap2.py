@@ -14,7 +14,7 @@ GEN = dict(temperature=1.0, top_k=250, top_p=0.92)
 q = model.draw_noise(256, B)
 a = torch.randn(8192, 8192, device="cuda"); b = torch.randn(8192, 8192, device="cuda")
 codes = model.sample(cond, GEN, True, q=q); torch.cuda.synchronize()
-s2 = torch.cuda.Stream()
+s2 = torch.cuda.Stream(); s1 = torch.cuda.Stream()
 def t(fn, n=2):
     fn(); torch.cuda.synchronize(); t0 = time.time()
     for _ in range(n): fn()
@@ -23,7 +23,12 @@ def mm():
     for _ in range(40): torch.mm(a, b)
 def vq():
     im = model.codes_to_images(codes); model.images_to_codes(im)
-def samp(): model.sample(cond, GEN, True, q=q)
+def samp():
+    if os.environ.get('SAMP_STREAM'):
+        with torch.cuda.stream(s1): model.sample(cond, GEN, True, q=q)
+        torch.cuda.current_stream().wait_stream(s1)
+    else:
+        model.sample(cond, GEN, True, q=q)
 def both(other):
     def f():
         # the second stream's work is enqueued FIRST: the 256 graph launches of the loop fill the hardware queue and block the host
