@@ -186,6 +186,84 @@ def parity_block(log):
     return out
 
 
+def secondary_block(log, device="cuda"):
+    """BASELINE.json configs[2] and configs[3] on the same GPU, AFTER the timed region and after the Taming engines are released
+    (driver-verifiable numbers for the two other model families; skip with --no-secondary):
+      * RAR-XL 256x256, batch 64 under guidance (128 rows), greenlist watermark and Gumbel key: sample 256 tokens -> MaskGIT-VQGAN
+        decode -> re-encode -> detect; floor = max(HBM, fp32 MFMA) per step of SURVEY Appendix F (1.15 ms HBM with every GEMM on the bf16 pipe);
+      * Chameleon/Anole-7B text -> image, batch 16 (48 sequences), 1024 image tokens at 512x512, greenlist (FIXED) watermark:
+        floor = (13.5 GB of bf16 weights + the bf16 KV rows of the step) / 8 TB/s.
+    Random-init weights of the real architectures; one warm-up + one timed repetition each."""
+    import gc
+    from wmar_amd.utils import synth
+    from wmar_amd.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
+    out = {}
+    sync = torch.cuda.synchronize
+
+    def run(model, wm, cond, gen, draw, n_steps):
+        best = None
+        for rep in range(2):
+            q = draw()
+            sync(); t0 = time.perf_counter()
+            codes = model.sample(cond, gen, apply_watermark=True, q=q) if q is not None else model.sample(cond, gen, apply_watermark=True)
+            sync(); t1 = time.perf_counter()
+            img = model.codes_to_images(codes); sync(); t2 = time.perf_counter()
+            c2 = model.images_to_codes(img); sync(); t3 = time.perf_counter()
+            pv = wm.detect(c2); sync(); t4 = time.perf_counter()
+            best = {"images_per_s": round(len(cond) / (t4 - t0), 3), "ms_per_step": round((t1 - t0) / n_steps * 1e3, 3),
+                    "sample_s": round(t1 - t0, 4), "vq_decode_s": round(t2 - t1, 4), "vq_encode_s": round(t3 - t2, 4), "detect_s": round(t4 - t3, 5),
+                    "token_match_after_roundtrip": round(float((c2 == codes).float().mean()), 4), "median_pvalue": float(pv.median())}
+        return best
+
+    try:
+        from wmar_amd.models.rar_wrapper import RarARMMWrapper
+        from wmar_amd.watermarking.gumbel_watermark import GumbelWatermark
+        m = RarARMMWrapper.synthetic(max_batch=B)
+        cond = torch.arange(B) % 1000
+        torch.manual_seed(0)
+        wm = GentimeWatermark(m.get_vq(), 1024, SeedStrategy.LINEAR, SplitStrategy.RANDOM_STRATIFIED, 1, 2.0, 0.25, device=device)
+        m.set_watermarker(wm)
+        r = run(m, wm, cond, None, lambda: m.draw_noise(B), 257)
+        # per step (128 rows, cache length 129.5 on average): 3.79 GB of fp32 weights + 5.43 GB of KV at 8 TB/s
+        floor_ms = (3.793e9 + 2 * 32 * 1280 * 4 * 129.5 * 128) / (PEAK_HBM_GBS * 1e9) * 1e3
+        r.update(config="RAR-XL 256x256, batch 64 x 2 guidance rows, greenlist delta=2 gamma=.25 h=1 + MaskGIT-VQGAN decode / encode + detect",
+                 step_floor_ms=round(floor_ms, 3), frac_of_step_floor=round(floor_ms / r["ms_per_step"], 3))
+        out["rar_xl_greenlist"] = r
+        gw = GumbelWatermark(1024, seed=1234, temperature=1.0, device=device)
+        m.set_watermarker(gw)
+        r = run(m, gw, cond, None, lambda: None, 257)
+        r.update(config="RAR-XL 256x256, batch 64 x 2 guidance rows, Gumbel key (extension: wmar_audio/watermark/engine.py semantics) + VQ decode / encode + detect",
+                 step_floor_ms=round(floor_ms, 3), frac_of_step_floor=round(floor_ms / r["ms_per_step"], 3))
+        out["rar_xl_gumbel"] = r
+        log(f"secondary RAR-XL: {out}")
+        del m, wm, gw
+        gc.collect(); torch.cuda.empty_cache()
+    except Exception as e:      # a secondary config must never cost the headline line
+        out["rar_xl_error"] = repr(e)
+    try:
+        from wmar_amd.models.chameleon_wrapper import ChameleonARMMWrapper
+        Bc, n_tok = 16, 1024
+        m = ChameleonARMMWrapper.synthetic(vq_cfg=synth.CHAMELEON_VQ, max_batch=Bc)
+        wm = GentimeWatermark(m.get_vq(), 65536, SeedStrategy.FIXED, SplitStrategy.RANDOM_STRATIFIED, 0, 2.0, 0.25, device=device)
+        m.set_watermarker(wm)
+        m.n_image_tokens = n_tok
+        text = m.vocab.text_tokens
+        cond = [(i, [text[(i * 37 + j * 11) % len(text)] for j in range(12 + i % 5)]) for i in range(Bc)]
+        r = run(m, wm, cond, {"temperature": 0.7, "top_p": 0.9}, lambda: m.draw_noise(Bc), n_tok + 17)
+        # per step: 13.5 GB of bf16 weights + 48 sequences x 2 x 32 x 4096 x 2 B x (17 + 512) cached rows on average
+        floor_ms = (13.48e9 + 48 * 2 * 32 * 4096 * 2 * 529.0) / (PEAK_HBM_GBS * 1e9) * 1e3
+        r.update(config="Chameleon/Anole-7B text->image 512x512 (1024 tokens), batch 16 x 3 guidance streams, greenlist (fixed key) "
+                        "delta=2 gamma=.25 + VQGAN-512 decode / encode + detect; ms_per_step includes ~17 prompt positions",
+                 step_floor_ms=round(floor_ms, 3), frac_of_step_floor=round(floor_ms / r["ms_per_step"], 3))
+        out["chameleon_7b"] = r
+        log(f"secondary Chameleon-7B: {r}")
+        del m, wm
+        gc.collect(); torch.cuda.empty_cache()
+    except Exception as e:
+        out["chameleon_7b_error"] = repr(e)
+    return out
+
+
 def default_engine(device, rank, args):
     """The product path: HIP engines on an MI355X (fails loudly anywhere else)."""
     from wmar_amd.models.taming_wrapper import TamingARMMWrapper
@@ -256,7 +334,10 @@ def gpu_analysis(model, wm, extra, cond, args, world, log):
     except Exception:
         pass
     roofline = {"bound": roles[dom]["bound"], "achieved": roles[dom]["achieved"], "peak": roles[dom]["peak"],
-                "unit": roles[dom]["unit"], "frac": roles[dom]["frac"], "traffic": traffic, "kernel": roles[dom]["kernel"],
+                "unit": roles[dom]["unit"], "frac": roles[dom]["frac"], "traffic": traffic,
+                "traffic_source": f"profiles/pmc_{dom}.json (committed rocprofv3 --pmc passes of this role: FETCH_SIZE x2 + WRITE_SIZE per launch; "
+                                  "not re-measured in this run)" if traffic is not None else None,
+                "kernel": roles[dom]["kernel"],
                 "avg_us": roles[dom]["avg_us"], "launches_per_step": per_step[dom],
                 "algorithmic_per_launch": roles[dom].get("bytes_per_launch", roles[dom].get("weight_bytes_per_launch")),
                 "share_of_decode_step": roles[dom]["share_of_decode_step"], "role": dom}
@@ -302,6 +383,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the RAR-XL / Chameleon-7B numbers (after the timed region)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -410,6 +492,13 @@ def main():
             out["cpu_baseline"] = None
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(extra["gs"], extra["vs"], extra["gcfg"], extra["vcfg"], wm, log)
+            out["secondary"] = None
+            if world == 1 and not args.no_secondary:
+                # the Taming engines (22.6 GB) are released first: the 7B model + its KV cache need 40 GB of their own
+                import gc
+                del model, wm, extra
+                gc.collect(); torch.cuda.empty_cache()
+                out["secondary"] = secondary_block(log, device)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
