@@ -301,6 +301,9 @@ def gpu_analysis(model, wm, extra, cond, args, world, log):
     share = {k: avg_us[k] * per_step[k] for k in per_step}
     tot = sum(share.values())
     names = eng.plan_info(B)                               # the kernels the engine selects for this batch (wmar_gpt_plan_info)
+    per_step["resid"] = int(names.get("resid_launches_per_step", L + 1))       # 1 when the projection launch folds the residual itself
+    share = {k: avg_us[k] * per_step[k] for k in per_step}
+    tot = sum(share.values())
     roles = {}
     for k in per_step:
         r = {"kernel": names.get(k, k), "avg_us": round(avg_us[k], 2), "launches_per_step": per_step[k],

@@ -167,10 +167,17 @@ int wmar_gpt_generate(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_para
 #define WMAR_T_HEAD 7    /* ln_f -> vocabulary head GEMM                       */
 #define WMAR_T_SAMPLE 8  /* fused watermark + sampling                         */
 #define WMAR_T_NCLASS 9
+/* Waits for `stream` and reports whether the XCD-local barrier of the fused projection launch (k_bx_xr: output projection +
+ * residual fold + LayerNorm statistics in one launch, batches of 33..64 rows) gave up or found a block on a foreign XCD since the
+ * last check.  WMAR_EHIP = the results of the calls since the last check are invalid; the engine continues on the two-launch path.
+ * wmar_gpt_create probes the block -> XCD grouping and only then enables the fused launch (WMAR_NO_XR=1 at creation disables it).
+ * The Python engine calls this after every generation.  No reference counterpart (no in-kernel synchronisation there). */
+int wmar_gpt_check(wmar_gpt* g, void* stream);
 int wmar_gpt_set_timing(wmar_gpt* g, int32_t enabled);
 /* Decode attention runs 1 / 2 / 4 waves per (sequence, head) while the cache holds <= one_wave_upto / <= two_waves_upto /
  * more rows (one captured step graph per phase).  Defaults were measured at batch 64 on MI355X; a tuning entry point only --
- * results do not depend on it beyond fp32 summation order across waves. */
+ * results do not depend on it beyond fp32 summation order across waves.  (-1, -1) returns to the automatic schedule (one wave at
+ * every length for batch x heads >= 512, 2 / 4 waves up to / beyond 128 cached rows below that). */
 int wmar_gpt_set_attention_phases(wmar_gpt* g, int32_t one_wave_upto, int32_t two_waves_upto);
 /* Replays ONE role's kernel `iters` times back to back on `stream` (cycling through the layers, so
  * weights stream from HBM as in a real step) between two HIP events: *avg_us = average per launch,
@@ -224,6 +231,13 @@ int wmar_rar_generate(wmar_rar* g, const wmar_wm_ctx* wm, const int64_t* class_i
 int wmar_rar_generate_gumbel(wmar_rar* g, const int64_t* class_ids_dev, int64_t B, const float* cfg_scale_host,
                              int32_t use_guidance, float temperature, float top_p, int32_t top_k,
                              const float* log_rs_dev, int64_t* tokens_out_dev, int32_t use_graph, void* stream);
+
+/* Waits for `stream` and reports whether an in-launch wait of the engine gave up since the last check (the fused residual +
+ * modulation launch of a RAR block lets its workgroups wait for each other's partial sums; wmar_rar_create verifies that the
+ * device holds them all at once, a wait that still gives up after 2^20 polls raises a device flag).  WMAR_EHIP = the results of
+ * the calls since the last check are invalid.  The Python engine calls it after every generation (no reference counterpart:
+ * the reference has no in-kernel synchronisation). */
+int wmar_rar_check(wmar_rar* g, void* stream);
 
 /* ----------------------------------------------------------------- Gumbel key (row G1)
  * Aaronson-style sampling of wmar_audio/watermark/engine.py:29-75 (`gumbel_sample`) and its

@@ -17,10 +17,10 @@ SYMBOLS = [
     "wmar_last_error", "wmar_version", "wmar_key_row_words", "wmar_key_table_rows", "wmar_key_table_build",
     "wmar_key_greenlist", "wmar_wm_process_logits", "wmar_sample_fused", "wmar_detect", "wmar_detect_num_ngrams",
     "wmar_gpt_create", "wmar_gpt_destroy", "wmar_gpt_device_bytes", "wmar_gpt_decode_step", "wmar_gpt_generate",
-    "wmar_gpt_set_timing", "wmar_gpt_set_attention_phases", "wmar_gpt_get_timing", "wmar_gpt_profile_role", "wmar_gpt_plan_info", "wmar_rar_create", "wmar_rar_destroy",
+    "wmar_gpt_set_timing", "wmar_gpt_set_attention_phases", "wmar_gpt_get_timing", "wmar_gpt_profile_role", "wmar_gpt_plan_info", "wmar_gpt_check", "wmar_rar_create", "wmar_rar_destroy",
     "wmar_rar_device_bytes", "wmar_rar_forward_position", "wmar_rar_generate", "wmar_vq_create", "wmar_vq_destroy", "wmar_vq_device_bytes",
     "wmar_vq_decode", "wmar_vq_encode", "wmar_mvq_create", "wmar_mvq_destroy", "wmar_mvq_device_bytes", "wmar_mvq_decode",
-    "wmar_mvq_encode", "wmar_gumbel_key_build", "wmar_gumbel_sample", "wmar_gumbel_score", "wmar_rar_generate_gumbel",
+    "wmar_mvq_encode", "wmar_gumbel_key_build", "wmar_gumbel_sample", "wmar_gumbel_score", "wmar_rar_generate_gumbel", "wmar_rar_check",
     "wmar_cham_create", "wmar_cham_destroy", "wmar_cham_device_bytes", "wmar_cham_forward_tokens", "wmar_cham_generate_image",
     "wmar_cham_sample",
 ]
@@ -129,6 +129,7 @@ def load():
     L.wmar_gpt_profile_role.argtypes = [vp, i32, i64, i32, i32, vp, C.POINTER(f64)]
     L.wmar_gpt_get_timing.argtypes = [vp, C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]
     L.wmar_gpt_plan_info.argtypes = [vp, i64, C.c_char_p, i64]
+    L.wmar_gpt_check.argtypes = [vp, vp]
     L.wmar_rar_create.argtypes = [C.POINTER(RarConfig), C.POINTER(C.c_char_p), C.POINTER(vp), i32, vp, C.POINTER(vp)]
     L.wmar_rar_destroy.argtypes = [vp]
     L.wmar_rar_destroy.restype = None
@@ -137,6 +138,7 @@ def load():
     L.wmar_rar_forward_position.argtypes = [vp, vp, vp, i64, i32, vp, vp]
     L.wmar_rar_generate.argtypes = [vp, C.POINTER(WmCtx), vp, i64, C.POINTER(f32), i32, f32, vp, vp, i32, vp]
     L.wmar_rar_generate_gumbel.argtypes = [vp, vp, i64, C.POINTER(f32), i32, f32, f32, i32, vp, vp, i32, vp]
+    L.wmar_rar_check.argtypes = [vp, vp]
     L.wmar_gumbel_key_build.argtypes = [C.c_uint64, i64, vp, vp, vp]
     L.wmar_gumbel_sample.argtypes = [vp, i64, i64, vp, i64, i32, f32, f32, i32, vp, vp]
     L.wmar_gumbel_score.argtypes = [vp, i64, i64, i64, vp, i64, vp, vp, vp]

@@ -266,7 +266,9 @@ __global__ __launch_bounds__(NWV * 64) void k_bgemm(BGemmArgs a) {
                 for (int i = 0; i < MT; ++i) {
                     if (EPI == BEPI_SLAB) {
                         const int piece = (int)blockIdx.x - sk_first(sk, g);
-                        if (i * 32 + (lane & 31) >= a.M) continue;      // padding rows: their partial sums are never stored (the slab buffers start zeroed)
+                        if (i * 32 + (lane & 31) >= a.M) continue;      // padding rows are never stored: a slot keeps zero (create-time memset) or the finite sums an earlier, larger batch left
+                                                                         // there.  Safe because every consumer works row by row (a row of the residual stream, of the SwiGLU product, of q/k/v
+                                                                         // depends on the same row only) and rows >= M are never read back as results or appended to the KV cache
 #pragma unroll
                         for (int b = 0; b < 2; ++b) {
                             float* dst = a.slabs + (long long)piece * a.slab_stride + ((((long long)nt * 2 + b) * MT + i) * 64 + lane) * 8;

@@ -1335,6 +1335,197 @@ static int launch_bx(const BxArgs& a, int N, hipStream_t st) {
 
 
 
+// ------------------------------------------------- output projection + residual fold + LN2 statistics in ONE launch (round 4)
+// k_bx<1, PER> for the attention output projection, with what k_resid_stats did as a launch of its own behind it (5 us x 48 layers)
+// moved INSIDE the launch behind an XCD-local barrier.
+//   * Block b runs on an XCD that depends on b % 8 only (measured on gfx950: XCC id = (b + r) % 8, r rotating with the launches
+//     before it; 24 of the 192 blocks on each XCD every time).  XCD group x = b % 8 owns column tiles 6x .. 6x+5 for ALL K slices: the
+//     S partial tiles of a column tile are then written and read through ONE L2.
+//   * phase 1 = k_bx: workgroup (tile, K slice) writes its partial tile to its slab with plain stores; s_waitcnt vmcnt(0) = the L2
+//     has them.
+//   * XCD-local barrier (scripts/xg_kernel.h, profiles/r04_xg_barrier_trace.log: 1.8 us): arrival counter and generation word are L2
+//     atomics WITHOUT sc1 -- they never leave the XCD -- polled with a returning L2 atomic.  The device-wide barrier of round 1 cost 17 us.
+//   * phase 2: the first four workgroups of the group (row tile x half of the group's 24 k-blocks) fold: x += bias + slab 0 + .. +
+//     slab S-1 in slab order (the arithmetic and order of k_resid_stats), and leave one (sum, sum of squares) per row and half for
+//     LayerNorm 2: statistics chunk 2 x + half of 16.  Loads bypass the L1 (nt): the slabs were written by other CUs of this XCD.
+// Safety: the engine probes the block -> XCD grouping at creation and otherwise keeps the two-launch path; in the launch, block c == 0
+// of a group publishes its XCC id and every block compares after the barrier (fail[0]); a wait that does not complete in 2^22 polls
+// raises fail[1] and goes on (wmar_gpt_check / the next call report it: the results are then invalid).  All 192 workgroups are
+// co-resident (one per CU).  Results never depend on timing: every sum has a fixed order.
+struct BxrArgs {
+    BxArgs bx;
+    float4* x;                 // packed residual stream [KB][2][64], updated in place
+    const float* bias;         // [N]
+    double* stats;             // [16][64][2]: chunk = 2 x XCD group + half
+    unsigned* sync;            // [8][64] words: word 0 arrivals, word 16 the group's XCC id, word 32 generation
+    unsigned* fail;            // [0] placement mismatch, [1] barrier timeout
+    int tiles_per_group;       // column tiles per XCD group (N / 32 / 8)
+};
+
+// the current value of a word as THIS XCD's L2 holds it (a compiler-level fetch_or(0) folds into a load that may hit the L1)
+__device__ __forceinline__ unsigned l2_read_u32(unsigned* p) {
+    unsigned v; const unsigned z = 0;
+    asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p), "v"(z) : "memory");
+    return v;
+}
+__device__ __forceinline__ unsigned xcc_id() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 15u;
+}
+static __global__ void k_xcc_probe(unsigned* o) { if (threadIdx.x == 0) o[blockIdx.x] = xcc_id(); }
+
+template <int PER, int S>
+__global__ __launch_bounds__(256) void k_bx_xr(BxrArgs q) {
+    constexpr int MTW = 2, XR = 3 * MTW, ROWS = 4 * MTW;
+    const BxArgs& a = q.bx;
+    __shared__ __attribute__((aligned(16))) float4 red[4][ROWS][64];
+    __shared__ double sred[4][64][2];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = (int)blockIdx.x & 7, c = (int)blockIdx.x >> 3;          // XCD group, member
+    const int tile = grp * q.tiles_per_group + c / S, ks = c % S;
+    unsigned gen0 = 0, xid = 0;
+    if (threadIdx.x == 0) {
+        xid = xcc_id();
+        if (c == 0) __hip_atomic_store(q.sync + grp * 64 + 16, xid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        gen0 = __hip_atomic_load(q.sync + grp * 64 + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // global_load sc1: served by the L2
+    }
+    // ---------------------------------------------------------------------------------------------------- phase 1 (k_bx<1, PER>)
+    {
+        const int u0 = (ks * 4 + w) * PER;
+        f32x16 acc[MTW];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        const float4* wp = a.Wq + ((long long)tile * a.KU + u0) * 128 + lane;
+        const u32x4* xp = a.Xq + (long long)u0 * XR * 64 + lane;
+        float4 wr[2];
+        u32x4 xr[XR];
+#define WMAR_BXR_LOADW(U) { wr[0] = ld_nt(wp + (long long)(U) * 128); wr[1] = ld_nt(wp + (long long)(U) * 128 + 64); }
+#define WMAR_BXR_LOADX(U) { _Pragma("unroll") for (int e = 0; e < XR; ++e) xr[e] = xp[(long long)(U) * (XR * 64) + e * 64]; }
+        WMAR_BXR_LOADW(0);
+        WMAR_BXR_LOADX(0);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 ph[2], pm[2], pl[2];
+        bx_split8(wr[0], wr[1], ph[0], pm[0], pl[0]);
+        if (1 < PER) WMAR_BXR_LOADW(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int cu = j & 1, n = cu ^ 1;
+            if (j + 1 < PER) {
+                bx_split8(wr[0], wr[1], ph[n], pm[n], pl[n]);
+                if (j + 2 < PER) WMAR_BXR_LOADW(j + 2);
+            }
+            bf16x8 x[XR];
+#pragma unroll
+            for (int e = 0; e < XR; ++e) x[e] = __builtin_bit_cast(bf16x8, xr[e]);
+#define WMAR_BXR_ROUND(WP, XP) _Pragma("unroll") for (int i = 0; i < MTW; ++i) WMAR_BX_MFMA(WP[cu], x[3 * i + XP], acc[i]);
+            WMAR_BXR_ROUND(pl, 0) WMAR_BXR_ROUND(ph, 2) WMAR_BXR_ROUND(pm, 1) WMAR_BXR_ROUND(pm, 0) WMAR_BXR_ROUND(ph, 1) WMAR_BXR_ROUND(ph, 0)
+#undef WMAR_BXR_ROUND
+            if (j + 1 < PER) WMAR_BXR_LOADX(j + 1);
+#pragma unroll
+            for (int i = 0; i < 6 * MTW; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                if (i % 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef WMAR_BXR_LOADW
+#undef WMAR_BXR_LOADX
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                red[w][i * 4 + g][lane] = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+        __syncthreads();
+        float4* out = a.out + (long long)ks * a.slab_stride;
+#pragma unroll
+        for (int r = 0; r < ROWS / 4; ++r) {
+            const int row = r * 4 + w, i = row >> 2, g = row & 3;
+            float4 v = red[0][row][lane];
+#pragma unroll
+            for (int o = 1; o < 4; ++o) { const float4 z = red[o][row][lane]; v.x += z.x; v.y += z.y; v.z += z.z; v.w += z.w; }
+            out[((long long)(tile * 4 + g) * MTW + i) * 64 + lane] = v;
+        }
+    }
+    // ---------------------------------------------------------------------------------------------------- XCD-local barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's slab stores are in the L2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* cnt = q.sync + grp * 64;
+        unsigned* gen = cnt + 32;
+        const unsigned members = (unsigned)(q.tiles_per_group * S);
+        // workgroup-scope atomics on global memory: global_atomic without sc1, performed by THIS XCD's L2
+        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (old == members - 1u) {
+            __hip_atomic_exchange(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            int spins = 0;
+            while (l2_read_u32(gen) == gen0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 22)) { __hip_atomic_store(q.fail + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        if (l2_read_u32(q.sync + grp * 64 + 16) != xid) __hip_atomic_store(q.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------------------------------------------- phase 2
+    if (c >= 2 * MTW) return;
+    {
+        // four workgroups fold: row tile mt = c & 1, half hp = c >> 1 of the group's k-blocks (12 of 24 at n_embd 1536: three per
+        // wave, ONE batch of 3 x (1 + S) loads) -> statistics chunk 2 grp + hp of 16
+        const int mt = c & 1, hp = c >> 1;
+        const int nkb = q.tiles_per_group * 2;                   // k-blocks (8 columns) of this half
+        const int kb_first = (grp * 2 + hp) * nkb;
+        const int half = lane >> 5;
+        double s = 0.0, ss = 0.0;
+        for (int k0 = w; k0 < nkb; k0 += 12) {
+            float4 v[3], sl[3][S], bb[3];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const int kb = kb_first + min(k0 + 4 * e, nkb - 4 + w);      // clamped (re-read; masked below)
+                const long long idx = ((long long)kb * MTW + mt) * 64 + lane;
+                v[e] = q.x[idx];
+                bb[e] = *(const float4*)(q.bias + kb * 8 + 4 * half);
+#pragma unroll
+                for (int si = 0; si < S; ++si) sl[e][si] = ld_nt(a.out + (long long)si * a.slab_stride + idx);
+            }
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                if (k0 + 4 * e >= nkb) continue;
+                const int kb = kb_first + k0 + 4 * e;
+                float4 t = sl[e][0];
+#pragma unroll
+                for (int si = 1; si < S; ++si) { t.x += sl[e][si].x; t.y += sl[e][si].y; t.z += sl[e][si].z; t.w += sl[e][si].w; }
+                // k_resid_stats: x + gate * (bias + sum), gate == 1
+                const float4 r = make_float4(v[e].x + (bb[e].x + t.x), v[e].y + (bb[e].y + t.y), v[e].z + (bb[e].z + t.z), v[e].w + (bb[e].w + t.w));
+                q.x[((long long)kb * MTW + mt) * 64 + lane] = r;
+                s += (double)r.x + (double)r.y + (double)r.z + (double)r.w;
+                ss += sq4_f64(r);         // never a v_fmac_f64 chain: common.h
+            }
+        }
+        sred[w][lane][0] = s; sred[w][lane][1] = ss;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            double ts = 0, tss = 0;
+            for (int i = 0; i < 4; ++i) { ts += sred[i][threadIdx.x][0] + sred[i][threadIdx.x + 32][0]; tss += sred[i][threadIdx.x][1] + sred[i][threadIdx.x + 32][1]; }
+            double* o = q.stats + ((long long)(grp * 2 + hp) * (MTW * 32) + mt * 32 + threadIdx.x) * 2;
+            o[0] = ts; o[1] = tss;
+        }
+    }
+}
+
+template <int PER, int S>
+static int launch_bx_xr(const BxrArgs& q, int N, hipStream_t st) {
+    hipLaunchKernelGGL((k_bx_xr<PER, S>), dim3((unsigned)(N / 32 * S)), dim3(256), 0, st, q);
+    return launch_status("k_bx_xr");
+}
+
 // --------------------------------------------------------------------- decode attention
 // One wave per (sequence, head).  K/V rows are hd floats; LPR = hd/4 lanes cover a row with
 // float4s and RPI = 64/LPR rows are read per wave-wide load (1 KiB, coalesced).

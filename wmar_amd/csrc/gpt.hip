@@ -88,6 +88,10 @@ struct wmar_gpt {
     static int phase_waves(int ph) { return ph == 0 ? 1 : (ph == 1 ? 2 : 4); }
     int timing = 0;
     bool no_bx_qkv = false, no_bx_proj = false;   // dev knobs WMAR_NO_BX_QKV / WMAR_NO_BX_PROJ
+    // fused output projection + residual fold + LN2 statistics (k_bx_xr): needs the block -> XCD grouping probed at creation
+    unsigned* xsync = nullptr;     // [8][64] barrier words, [8*64 ..] = fail flags (placement, timeout)
+    bool xcd_ok = false;           // blocks with equal blockIdx % 8 share an XCD, eight distinct XCDs (k_xcc_probe)
+    bool no_xr = false;            // WMAR_NO_XR=1 at creation: keep the two-launch path
     unsigned long long* dbg_sums = nullptr; int dbg_slot = 0;   // dev only: see k_dbg_sum
     bool no_bx = false;           // dev knob WMAR_NO_BX: keep the fp32-MFMA k_qkvx
     int force_s[3] = {0, 0, 0};   // tuning knobs: WMAR_S_QKV / WMAR_S_PROJ / WMAR_S_FC2
@@ -188,6 +192,8 @@ struct StepPlan {
     int S_qx = 0;
     float4* xcur = nullptr;   // residual stream buffer the next launch reads (the fused fold ping-pongs between x and x2)
     bool proj_bx = false;     // 33..64 rows, n_embd a multiple of 384: output projection as k_bx on the attention's bf16 pieces
+    bool proj_xr = false;     // ... with the residual fold + LN2 statistics inside the launch (k_bx_xr): no k_resid_stats behind it
+    int nch_ln2 = 0;          // statistics chunks the FC1 launch reads (16 = two per XCD group behind k_bx_xr)
 
     StepPlan(wmar_gpt* g_, int64_t B_, const StepIO& io_, hipStream_t st_) : g(g_), B(B_), io(io_), st(st_) {
         MT = mt_for(B); D = g->D; KBD = D / 8; KBF = 4 * D / 8; nch = stat_chunks(KBD);
@@ -220,6 +226,8 @@ struct StepPlan {
         }
         proj_bx = MT == 2 && g->yq && g->layers[0].wproj_bx && !g->no_bx && !g->no_bx_proj && g->force_s[1] <= 0;
         if (proj_bx) S_proj = D / BX_KSLICE;
+        proj_xr = proj_bx && g->xcd_ok && !g->no_xr && S_proj == 4 && (D / 32) % 8 == 0 && (D / 32 / 8) * S_proj <= 32 && (D / 32 / 8) % 2 == 0;
+        nch_ln2 = proj_xr ? 16 : nch;
     }
     void dbg(const void* p, long long bytes) {
 #ifdef WMAR_DEV_KNOBS
@@ -229,6 +237,9 @@ struct StepPlan {
         (void)p; (void)bytes;
 #endif
     }
+    // the predicates the launches below use (wmar_gpt_plan_info reports from the same ones)
+    bool qkv_bx() const { return S_qx > 0 && MT == 2 && g->layers[0].wqkvx_bx && !g->no_bx && !g->no_bx_qkv; }
+    bool fc1_x() const { return MT == 2 && g->layers[0].wfc1x16; }
     int split_for(int NT, int KB) const { return pick_split(MT % 2 == 0 ? NT * (MT / 2) : NT * MT, KB, 4); }
     GemmArgs base() const {
         GemmArgs a{};
@@ -271,7 +282,7 @@ struct StepPlan {
         q.cap = ((q.NT / 4) * q.S + 7) / 8;
         g->span_begin(WMAR_T_QKV, st);
         int rc;
-        if (MT == 2 && w.wqkvx_bx && !g->no_bx && !g->no_bx_qkv) { q.Wp = w.wqkvx_bx; rc = launch_qkvx_bx(q, S_in, st); }   // 33..64 rows: bf16 matrix pipe
+        if (qkv_bx()) { q.Wp = w.wqkvx_bx; rc = launch_qkvx_bx(q, S_in, st); }   // 33..64 rows: bf16 matrix pipe
         else rc = launch_qkvx(q, MT, S_in, st);
         g->span_end(st);
         xcur = xout;
@@ -321,6 +332,17 @@ struct StepPlan {
     }
     // attention output projection (split-K slabs; bias + residual folded by the next resid())
     int proj(int l) {
+        if (proj_xr) {
+            BxrArgs q{};
+            BxArgs& x = q.bx;
+            x.Wq = g->layers[l].wproj_bx; x.Xq = g->yq; x.out = g->slabs; x.slab_stride = act; x.KU = D / 16; x.S = 4;
+            q.x = xcur; q.bias = g->layers[l].bproj; q.stats = g->stats; q.sync = g->xsync; q.fail = g->xsync + 8 * 64;
+            q.tiles_per_group = D / 32 / 8;
+            g->span_begin(WMAR_T_PROJ, st);
+            const int rc = launch_bx_xr<BX_PER, 4>(q, D, st);
+            g->span_end(st);
+            return rc;
+        }
         if (proj_bx) {
             BxArgs x{};
             x.Wq = g->layers[l].wproj_bx; x.Xq = g->yq; x.out = g->slabs; x.slab_stride = act; x.KU = D / 16; x.S = D / BX_KSLICE;
@@ -343,12 +365,12 @@ struct StepPlan {
         GemmArgs f = base();
         const LayerW& w = g->layers[l];
         f.Wp = w.wfc1; f.Xp = xcur; f.bias = w.bfc1; f.c1 = w.cfc1; f.KB = KBD; f.NT = 4 * D / 32;
-        f.out_packed = g->hbuf; f.slab_stride = 0;
+        f.out_packed = g->hbuf; f.slab_stride = 0; f.n_chunks = nch_ln2;
         g->span_begin(WMAR_T_FC1, st);
         int rc;
-        if (MT == 2 && w.wfc1x16) {
+        if (fc1_x()) {
             Fc1xArgs x{};
-            x.W16 = w.wfc1x16; x.W8 = w.wfc1x8; x.Xp = xcur; x.bias = w.bfc1; x.c1 = w.cfc1; x.stats = g->stats; x.n_chunks = nch; x.K = D;
+            x.W16 = w.wfc1x16; x.W8 = w.wfc1x8; x.Xp = xcur; x.bias = w.bfc1; x.c1 = w.cfc1; x.stats = g->stats; x.n_chunks = nch_ln2; x.K = D;
             x.out = g->hbuf; x.KU = D / 16;
             hipLaunchKernelGGL(k_fc1x, dim3((unsigned)(4 * D / 24)), dim3(256), 0, st, x);
             rc = launch_status("k_fc1x");
@@ -420,8 +442,8 @@ int enqueue_step(wmar_gpt* g, int64_t B, const StepIO& io, hipStream_t st) {
         }
         if ((rc = p.proj(l))) return rc;
         p.dbg(g->slabs, p.S_proj * actb);                                                                        // +6 proj slabs
-        if ((rc = p.resid(g->layers[l].bproj, p.S_proj))) return rc;
-        p.dbg(p.xcur, actb); p.dbg(g->stats, p.nch * Mpad * 16);                                                 // +7, +8
+        if (!p.proj_xr && (rc = p.resid(g->layers[l].bproj, p.S_proj))) return rc;             // k_bx_xr has folded and summed already
+        p.dbg(p.xcur, actb); p.dbg(g->stats, p.nch_ln2 * Mpad * 16);                                             // +7, +8
         if ((rc = p.fc1(l))) return rc;
         p.dbg(g->hbuf, 4 * actb);                                                                                // +9 hidden
         if ((rc = p.fc2(l))) return rc;
@@ -572,6 +594,7 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
     TRY(g->alloc(&g->scratch, (size_t)g->Bmax * V));
     TRY(g->alloc(&g->past, (size_t)g->Bmax * (g->Tmax + 1)));
     TRY(g->alloc(&g->pos_dev, 4));
+    TRY(g->alloc(&g->xsync, 8 * 64 + 64));
     g->step_dev = g->pos_dev + 1;
     if (rc == WMAR_OK) {
         // padded rows of the packed buffers must hold finite numbers
@@ -584,6 +607,7 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
         if (e == hipSuccess) e = hipMemsetAsync(g->y, 0, Mpad * D * 4, st);
         if (e == hipSuccess) e = hipMemsetAsync(g->qbuf, 0, Mpad * D * 4, st);
         if (e == hipSuccess && g->yq) e = hipMemsetAsync(g->yq, 0, (size_t)D / 16 * 2 * 3 * 64 * 16, st);   // rows past the batch are never written
+        if (e == hipSuccess) e = hipMemsetAsync(g->xsync, 0, (8 * 64 + 64) * 4, st);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->cap_stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreate(&g->ev0);
         if (e == hipSuccess) e = hipEventCreate(&g->ev1);
@@ -591,9 +615,50 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
         if (e != hipSuccess) { set_error("gpt_create: %s", hipGetErrorString(e)); rc = WMAR_EHIP; }
     }
 #undef TRY
+    if (rc == WMAR_OK && g->MTmax >= 2 && g->yq) {
+        // k_bx_xr keeps a split-K reduction inside an XCD: probe that the 24 blocks of a 192-block grid with equal blockIdx % 8
+        // share an XCC id and that the eight groups land on eight different XCDs (three launches: the id a group gets rotates with
+        // the launches before it, the grouping must not).  Anything else keeps the two-launch path.
+        g->no_xr = getenv("WMAR_NO_XR") != nullptr;
+        unsigned* probe = g->xsync + 8 * 64 + 16;      // scratch behind the fail words is too small: use a temporary
+        unsigned* tmp = nullptr;
+        bool ok = hipMalloc(&tmp, 192 * 4) == hipSuccess;
+        (void)probe;
+        for (int rep = 0; rep < 3 && ok; ++rep) {
+            unsigned h[192];
+            hipLaunchKernelGGL(k_xcc_probe, dim3(192), dim3(256), 0, st, tmp);
+            ok = hipMemcpyAsync(h, tmp, sizeof h, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+            unsigned seen = 0;
+            for (int b = 0; b < 192 && ok; ++b) ok = h[b] == h[b & 7] && h[b] < 16;
+            for (int x = 0; x < 8 && ok; ++x) { ok = !(seen & (1u << h[x])); seen |= 1u << h[x]; }
+        }
+        if (tmp) (void)hipFree(tmp);
+        g->xcd_ok = ok;
+    }
     if (rc != WMAR_OK) { delete g; return rc; }
     *out = g;
     return WMAR_OK;
+}
+
+// The fused projection launch (k_bx_xr) raises device flags when its XCD-local barrier gives up or a block sits on a foreign XCD.
+static int gpt_sync_status(wmar_gpt* g, hipStream_t st) {
+    if (!g->xsync) return WMAR_OK;
+    unsigned f[2] = {0, 0};
+    WMAR_HIP_CHECK(hipMemcpyAsync(f, g->xsync + 8 * 64, 8, hipMemcpyDeviceToHost, st));
+    WMAR_HIP_CHECK(hipStreamSynchronize(st));
+    if (f[0] || f[1]) {
+        g->drop_graph();
+        (void)hipMemsetAsync(g->xsync, 0, (8 * 64 + 64) * 4, st);
+        g->xcd_ok = false;                  // the two-launch path from here on
+        set_error("gpt: the XCD-local barrier of the fused projection launch %s: the results of the calls since the last check are invalid "
+                  "(the engine continues on the two-launch path)", f[0] ? "found a block on a foreign XCD" : "timed out");
+        return WMAR_EHIP;
+    }
+    return WMAR_OK;
+}
+int wmar_gpt_check(wmar_gpt* g, void* stream) {
+    WMAR_REQUIRE(g, "gpt_check: null argument");
+    return gpt_sync_status(g, (hipStream_t)stream);
 }
 
 void wmar_gpt_destroy(wmar_gpt* g) { delete g; }
@@ -661,18 +726,26 @@ int wmar_gpt_plan_info(wmar_gpt* g, int64_t B, char* buf, int64_t buf_len) {
     StepIO io{g->past, (long long)g->Tmax + 1, 0, g->logits};
     StepPlan p(g, B, io, nullptr);
     const LayerW& w = g->layers[0];
-    char qkv[96], proj[96], fc1[96], fc2[96];
+    char qkv[96], proj[160], fc1[96], fc2[96];
     const int S_in = p.S_fc2 + (p.fc2_hi > 0 ? 1 : 0);
-    if (p.S_qx > 0 && p.MT == 2 && w.wqkvx_bx && !g->no_bx) snprintf(qkv, sizeof qkv, "k_qkvx_bx<%d> (bf16 pipe, %d K slices)", S_in, p.S_qx);
+    (void)w;
+    if (p.qkv_bx()) snprintf(qkv, sizeof qkv, "k_qkvx_bx<%d> (bf16 pipe, %d K slices)", S_in, p.S_qx);
     else if (p.S_qx > 0) snprintf(qkv, sizeof qkv, "k_qkvx<%d,%d> (fp32 MFMA, %d K slices)", p.MT, S_in, p.S_qx);
     else snprintf(qkv, sizeof qkv, "k_gemm<EPI_PACKED> (fp32 MFMA, %d K slices) after k_resid_stats", p.S_qkv);
-    if (p.proj_bx) snprintf(proj, sizeof proj, "k_bx<1,%d> (bf16 pipe, %d K slices)", BX_PER, p.S_proj);
+    if (p.proj_xr) snprintf(proj, sizeof proj, "k_bx_xr<%d,4> (bf16 pipe, 4 K slices + XCD-local reduction: residual fold and LN2 statistics inside)", BX_PER);
+    else if (p.proj_bx) snprintf(proj, sizeof proj, "k_bx<1,%d> (bf16 pipe, %d K slices)", BX_PER, p.S_proj);
     else snprintf(proj, sizeof proj, "k_gemm<EPI_PACKED> (fp32 MFMA, %d K slices)", p.S_proj);
-    if (p.MT == 2 && w.wfc1x16) snprintf(fc1, sizeof fc1, "k_fc1x (fp32 MFMA, 24-column tiles, whole K)");
+    if (p.fc1_x()) snprintf(fc1, sizeof fc1, "k_fc1x (fp32 MFMA, 24-column tiles, whole K)");
     else snprintf(fc1, sizeof fc1, "k_gemm<EPI_GELU,LN> (fp32 MFMA, whole K)");
     snprintf(fc2, sizeof fc2, "k_gemm<EPI_PACKED> (fp32 MFMA, %d%s K slices)", p.S_fc2, p.fc2_hi > 0 ? "/+1" : "");
-    const int n = snprintf(buf, (size_t)buf_len, "qkv=%s;attn=k_attn_decode<%d,%d>;proj=%s;resid=k_resid_stats;fc1=%s;fc2=%s;head=k_gemm<EPI_LOGITS,LN> (fp32 MFMA)",
-                           qkv, g->hd, wmar_gpt::phase_waves(g->att_phase(g->Tmax / 2, B)), proj, fc1, fc2);
+    // attention: the waves per (sequence, head) follow the cache length (att_phase); reported at 1, block_size / 2 and block_size rows
+    char attn[96];
+    const int w0 = wmar_gpt::phase_waves(g->att_phase(1, B)), w1 = wmar_gpt::phase_waves(g->att_phase(g->Tmax / 2, B)),
+              w2 = wmar_gpt::phase_waves(g->att_phase(g->Tmax, B));
+    if (w0 == w1 && w1 == w2) snprintf(attn, sizeof attn, "k_attn_decode<%d,%d>", g->hd, w1);
+    else snprintf(attn, sizeof attn, "k_attn_decode<%d,%d> (%d / %d / %d waves at 1 / %d / %d cached rows)", g->hd, w1, w0, w1, w2, g->Tmax / 2, g->Tmax);
+    const int n = snprintf(buf, (size_t)buf_len, "qkv=%s;attn=%s;proj=%s;resid=k_resid_stats;resid_launches_per_step=%d;fc1=%s;fc2=%s;head=k_gemm<EPI_LOGITS,LN> (fp32 MFMA)",
+                           qkv, attn, proj, p.proj_xr ? 1 : g->L + 1, fc1, fc2);
     WMAR_REQUIRE(n > 0 && n < buf_len, "plan_info: buffer of %lld bytes too small", (long long)buf_len);
     return WMAR_OK;
 }
@@ -703,8 +776,14 @@ int wmar_gpt_debug_kv_row(wmar_gpt* g, int which, int pos, float* out) {
 
 
 int wmar_gpt_set_attention_phases(wmar_gpt* g, int32_t one_wave_upto, int32_t two_waves_upto) {
-    WMAR_REQUIRE(g && one_wave_upto >= 0 && two_waves_upto >= one_wave_upto, "set_attention_phases: bad thresholds");
-    if (g->att_t1 != one_wave_upto || g->att_t2 != two_waves_upto) g->drop_graph();
+    WMAR_REQUIRE(g, "set_attention_phases: null argument");
+    if (one_wave_upto < 0 && two_waves_upto < 0) {          // (-1, -1): back to the automatic schedule (batch-dependent, att_phase)
+        if (g->att_user) g->drop_graph();
+        g->att_t1 = 1 << 30; g->att_t2 = 1 << 30; g->att_user = false;
+        return WMAR_OK;
+    }
+    WMAR_REQUIRE(one_wave_upto >= 0 && two_waves_upto >= one_wave_upto, "set_attention_phases: bad thresholds");
+    if (!g->att_user || g->att_t1 != one_wave_upto || g->att_t2 != two_waves_upto) g->drop_graph();
     g->att_t1 = one_wave_upto; g->att_t2 = two_waves_upto; g->att_user = true;
     return WMAR_OK;
 }

@@ -490,9 +490,12 @@ struct RarPlan {
         a.kb_gate = off_gate / 8; a.kb_shift = off_shift / 8; a.kb_scale = off_scale / 8; a.mod_stride = g->Ntot;
         if (shared_u) { a.gate_u = g->mod_u + off_gate; a.shift_u = g->mod_u + off_shift; a.scale_u = g->mod_u + off_scale; a.split = Bhalf; }
         a.h = g->h; a.hq = planes;
-        a.part = g->part + (size_t)site * g->part_site; a.fail = g->sync_fail;
+        a.part = g->part + (size_t)site * site_words(); a.fail = g->sync_fail;
         return launch_resid_mod(a, nrm * MT, kpw, st);
     }
+    // words of one k_resid_mod launch site at THIS plan's row count: [chunks][32 MT][2]; the sites are packed at this size, so the
+    // poison memset of a position covers exactly what the launches poll
+    size_t site_words() const { const int kpw = KBD <= 256 ? 1 : 4; return (size_t)((KBD + 4 * kpw - 1) / (4 * kpw)) * MT * 32 * 2; }
     bool fc1_bx() const {
         return bx && g->bx_fc1
 #ifdef WMAR_DEV_KNOBS
@@ -590,7 +593,7 @@ struct RarPlan {
     }
     int position(bool with_head, float* logits_out) {
         int rc;
-        if (hipMemsetAsync(g->part, 0xff, (size_t)2 * g->L * g->part_site * 8, st) != hipSuccess) {     // poison: "not published yet"
+        if (hipMemsetAsync(g->part, 0xff, (size_t)2 * g->L * site_words() * 8, st) != hipSuccess) {     // poison: "not published yet"
             set_error("rar position: poisoning the partial sums failed"); return WMAR_EHIP;
         }
         if ((rc = embed())) return rc;
@@ -652,9 +655,8 @@ int wmar_rar_create(const wmar_rar_config* cfg, const char* const* names, const 
         g->bx_fc1 = D == 1280 && F % 32 == 0 && F / 32 <= 256;
         g->bx_ok = D % 64 == 0 && g->bx_qkv.S > 0 && g->bx_qkv.S <= QKV_SLABS_MAX && g->bx_proj.S > 0 && g->bx_fc2.S > 0;
     }
-#ifdef WMAR_DEV_KNOBS
+    // WMAR_NO_BX=1 at engine creation (any build, as in gpt.hip): every GEMM stays on the fp32-input MFMA kernels
     g->no_bx = getenv("WMAR_NO_BX") != nullptr;
-#endif
     g->layers.resize(L);
     for (int l = 0; l < L && rc == WMAR_OK; ++l) {
         const std::string p = "blocks." + std::to_string(l) + ".";
@@ -731,6 +733,25 @@ int wmar_rar_create(const wmar_rar_config* cfg, const char* const* names, const 
     { const int kbd = D / 8, kpw = kbd <= 256 ? 1 : 4; g->part_site = (size_t)((kbd + 4 * kpw - 1) / (4 * kpw)) * g->MTmax * 32 * 2; }
     TRY(g->alloc(&g->part, (size_t)2 * L * g->part_site));
     TRY(g->alloc(&g->sync_fail, 4));
+    if (rc == WMAR_OK && hipMemsetAsync(g->sync_fail, 0, 16, st) != hipSuccess) { set_error("rar_create: memset failed"); rc = WMAR_EHIP; }
+    if (rc == WMAR_OK) {
+        // k_resid_mod's workgroups wait for each other's partial sums inside ONE launch: every workgroup of its grid (chunks x row
+        // tiles, at most 64 x 4) must be resident at the same time.  Checked here against what the device can hold (the occupancy
+        // the runtime reports for the widest instantiation x the compute units it exposes -- a CU mask or a partition mode shrinks
+        // it); a device that cannot is refused loudly instead of risking a stall.  A wait that gives up at run time (2^20 polls)
+        // sets sync_fail, which wmar_rar_check and every later call report.
+        int nb = 0, dev = 0, cus = 0;
+        hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_resid_mod<8, 4>, 256, 0);
+        if (e1 == hipSuccess) e1 = hipGetDevice(&dev);
+        if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int kbd = D / 8, kpw = kbd <= 256 ? 1 : 4;
+        const long long need = (long long)((kbd + 4 * kpw - 1) / (4 * kpw)) * g->MTmax;
+        if (e1 != hipSuccess) { set_error("rar_create: occupancy query failed: %s", hipGetErrorString(e1)); rc = WMAR_EHIP; }
+        else if ((long long)nb * cus < need) {
+            set_error("rar_create: the fused residual + modulation launch needs %lld co-resident workgroups, the device holds %d x %d", need, nb, cus);
+            rc = WMAR_EINVAL;
+        }
+    }
     if (rc == WMAR_OK) {
         hipError_t er = hipMemsetAsync(g->x, 0, Mpad * D * 4, st);
         if (er == hipSuccess) er = hipMemsetAsync(g->h, 0, Mpad * D * 4, st);
@@ -754,6 +775,23 @@ int wmar_rar_create(const wmar_rar_config* cfg, const char* const* names, const 
 }
 
 void wmar_rar_destroy(wmar_rar* g) { delete g; }
+
+// The in-launch waits of k_resid_mod raise g->sync_fail when they give up; the results of that call are then invalid.
+static int rar_sync_status(wmar_rar* g, hipStream_t st) {
+    unsigned f = 0;
+    WMAR_HIP_CHECK(hipMemcpyAsync(&f, g->sync_fail, 4, hipMemcpyDeviceToHost, st));
+    WMAR_HIP_CHECK(hipStreamSynchronize(st));
+    if (f) {
+        (void)hipMemsetAsync(g->sync_fail, 0, 4, st);
+        set_error("rar: an in-launch wait of k_resid_mod gave up (its workgroups were not co-resident): the results of the previous call are invalid");
+        return WMAR_EHIP;
+    }
+    return WMAR_OK;
+}
+int wmar_rar_check(wmar_rar* g, void* stream) {
+    WMAR_REQUIRE(g, "rar_check: null argument");
+    return rar_sync_status(g, (hipStream_t)stream);
+}
 int64_t wmar_rar_device_bytes(const wmar_rar* g) { return g ? g->mem.bytes : 0; }
 
 int wmar_rar_forward_position(wmar_rar* g, const int64_t* tok_dev, const int64_t* cond_ids_dev, int64_t M, int32_t pos,

@@ -79,6 +79,8 @@ class GPTEngine:
                 self._h, C.byref(wm_ctx) if wm_ctx is not None else None, C.byref(sp), cond.data_ptr(), B, int(steps),
                 q.data_ptr(), out.data_ptr(), trace.data_ptr() if trace is not None else None,
                 _lib.stream_ptr(self.device)))
+            # waits for the replays; raises if the fused projection launch's in-kernel barrier gave up (results invalid)
+            _lib.check(self._L.wmar_gpt_check(self._h, _lib.stream_ptr(self.device)))
         return (out, trace) if trace_logits else out
 
     def profile_role(self, role: str, B: int, kv_len: int = 128, iters: int = 96) -> float:
@@ -242,6 +244,7 @@ class RAREngine:
                 self._h, C.byref(wm_ctx) if wm_ctx is not None else None, class_ids.data_ptr(), B,
                 C.cast(sc.data_ptr(), C.POINTER(C.c_float)) if sc is not None else None, 1 if sc is not None else 0,
                 float(temperature), q.data_ptr(), out.data_ptr(), 1 if use_graph else 0, _lib.stream_ptr(self.device)))
+            _lib.check(self._L.wmar_rar_check(self._h, _lib.stream_ptr(self.device)))      # waits; raises if an in-launch wait gave up
         return out
 
     def generate_gumbel(self, class_ids, log_rs, cfg_scales, temperature=1.0, top_p=0.0, top_k=0, use_graph=True):
@@ -262,6 +265,7 @@ class RAREngine:
                 self._h, class_ids.data_ptr(), B, C.cast(sc.data_ptr(), C.POINTER(C.c_float)) if sc is not None else None,
                 1 if sc is not None else 0, float(temperature), float(top_p), int(top_k), log_rs.data_ptr(), out.data_ptr(),
                 1 if use_graph else 0, _lib.stream_ptr(self.device)))
+            _lib.check(self._L.wmar_rar_check(self._h, _lib.stream_ptr(self.device)))
         return out
 
 
