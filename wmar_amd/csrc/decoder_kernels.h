@@ -1811,4 +1811,253 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
 #endif
 }
 
+// ------------------------------------------------- decode attention at head_dim 80 (RAR-XL), every lane busy (round 4)
+// k_attn_decode lays a cache row on the next power of two of lanes: at head_dim 80 that is 32 lanes of which 20 carry data -- 3/8 of
+// every load instruction, dot product and shuffle idle, 40 us x 32 blocks = 31 % of the RAR-XL step.  Here a row is cut into a MAIN
+// part of 64 floats (16 lanes x float4: 4 rows per 1-KiB load) and a TAIL of 16 floats (4 lanes x float4: 16 rows per load): 16 cached
+// rows are 4 + 1 loads of K and 4 + 1 of V with all 64 lanes carrying data (10 KiB per 16 rows instead of 16 KiB of load slots).
+// A lane plays both roles.  Main load u (0..3) holds rows 4u + g in lane group g = lane / 16; the tail load holds row
+// 4 ((lane / 4) % 4) + lane / 16 in lane quad lane / 4 -- i.e. a tail lane's row is the row of ITS OWN lane group for u = (lane / 4) % 4,
+// so it picks the main partial score out of its own registers (3 selects, no cross-lane traffic), and a main lane fetches the tail
+// partial of row (u, g) from lane 16 g + 4 u of its own 16-lane row (one __shfl per main load).  The prologue (QKV pieces, bias,
+// q / k LayerNorm over the 80 values, cache append) is k_attn_decode's.
+template <int NWA>
+__global__ __launch_bounds__(NWA * 64) void k_attn_decode80(AttnArgs a) {
+    constexpr int HD = 80, LPRA = 20, LPR = 32, RPI = 2, ROWS = 16;
+    __shared__ __attribute__((aligned(16))) float part[NWA][HD + 4];
+    __shared__ __attribute__((aligned(16))) float qkv_s[3][HD];
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int T = *a.pos_dev + 1;
+    // prologue roles (k_attn_decode's layout: 32 lanes per row, 20 active)
+    const int subr = lane % LPR, rsel = lane / LPR;
+    const bool lane_on = subr < LPRA;
+    const int sub = lane_on ? subr : 0;
+    float* Kc = a.kcache + ((long long)b * a.H + h) * a.Tmax * HD;
+    float* Vc = a.vcache + ((long long)b * a.H + h) * a.Tmax * HD;
+    const int nchunk = (T + ROWS - 1) / ROWS;
+    // streaming roles
+    const int g16 = lane >> 4, m16 = lane & 15;              // main: row 4u + g16, floats 4 m16 .. + 3
+    const int ut = (lane >> 2) & 3, t4 = lane & 3;           // tail: row 4 ut + g16, floats 64 + 4 t4 .. + 3
+    const float* Kmain = Kc + m16 * 4;
+    const float* Vmain = Vc + m16 * 4;
+    const float* Ktail = Kc + 64 + t4 * 4;
+    const float* Vtail = Vc + 64 + t4 * 4;
+    // rows past T-1 are clamped to T-1 and replaced from registers / masked below
+#define WMAR_A80_LOAD(KM, KT, VM, VT, C0)                                                \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                      \
+        const int t = min((C0) * ROWS + 4 * u + g16, T - 1);                             \
+        KM[u] = *(const float4*)(Kmain + (long long)t * HD);                             \
+        VM[u] = *(const float4*)(Vmain + (long long)t * HD);                             \
+    }                                                                                    \
+    { const int t = min((C0) * ROWS + 4 * ut + g16, T - 1);                              \
+      KT = *(const float4*)(Ktail + (long long)t * HD);                                  \
+      VT = *(const float4*)(Vtail + (long long)t * HD); }
+    float4 kmA[4], vmA[4], ktA, vtA, kmB[4], vmB[4], ktB, vtB;
+    // PF2: the wave's first TWO chunks are requested before the prologue (32 KiB in flight per wave: with 1 / 2 / 4 waves the
+    // whole cache up to 64 / 128 / 256 rows streams while q/k/v are finished); otherwise one, the second from inside the loop.
+    // (Measured dead end: clamping the first chunk to the cache's capacity instead of its fill, so that its loads need not wait
+    // for the scalar load of the position, saves 1.3 us at 64 rows and costs 3 us below 32 rows -- stale rows are then streamed.)
+    // The prologue's loads go FIRST: loads return in issue order, so behind 16 KiB of cache rows per wave the QKV pieces would
+    // arrive only after the chip-wide burst of first chunks has drained (~4 us); ahead of it they are back in ~1.5 us and q, k, v
+    // are finished while the first chunk is still in flight.
+    // every load of the prologue is issued before the first wait: LN partial sums (one chunk per
+    // lane), the QKV slab(s), the folded-LN row sums and the bias (16 lanes each)
+    const int Mpad = a.MT * 32;
+    const int mt = b >> 5;
+    double sm = 0, sq = 0;
+    // Every prologue load is UNCONDITIONAL per lane (indices clamped, unused values masked where they are summed): a load under a
+    // per-lane condition (`cond ? load : 0`) compiles to an exec-masked branch whose result is merged right behind it, i.e. one
+    // `s_waitcnt vmcnt(0)` per load -- a dozen serialized L2 round trips instead of one (round 3: the ISA showed exactly that).
+    double2 st0 = make_double2(0.0, 0.0);
+    if (w == 0) st0 = *(const double2*)(a.stats + ((long long)min(lane, a.n_chunks - 1) * Mpad + b) * 2);
+    // The S split-K pieces of this head's 3 x hd columns are spread over the wave's RPI row groups (piece p is fetched by
+    // group p % RPI), so that a lane holds at most PMAX pieces: all loads are still in flight together, without 3 x 8
+    // float4 registers per lane (the kernel's occupancy is set by its registers).  The partial sums meet in a fixed
+    // xor-butterfly over the groups: the summation order depends on S only.
+    constexpr int PMAX = (QKV_SLABS_MAX + RPI - 1) / RPI;
+    float4 sl[3][PMAX], cc[3], bb[3];
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+        const int n = which * a.D + h * HD + sub * 4;          // first of this lane's 4 columns
+        const long long idx = ((long long)(n >> 3) * a.MT + mt) * 64 + (b & 31) + 32 * ((n >> 2) & 1);
+        if (w == 0) {           // wave-uniform
+#pragma unroll
+            for (int pi = 0; pi < PMAX; ++pi) {
+                const int pc = min(rsel + pi * RPI, a.S - 1);
+                sl[which][pi] = a.qkv_slabs[(long long)pc * a.slab_stride + idx];
+            }
+            cc[which] = *(const float4*)((a.mode == 0 ? a.c1 : a.bias) + n);     // (mode 1 has no c1: any valid address, value unused)
+            bb[which] = *(const float4*)(a.bias + n);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    WMAR_A80_LOAD(kmA, ktA, vmA, vtA, w)
+    __builtin_amdgcn_sched_barrier(0);
+    if (w == 0) {
+        sm = lane < a.n_chunks ? st0.x : 0.0; sq = lane < a.n_chunks ? st0.y : 0.0;
+        // (n_chunks <= STAT_CHUNKS_MAX = 64: one chunk per lane; a loop over further chunks here would put a load in a loop and make
+        // hipcc wait for ALL outstanding loads, the first cache chunk included)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
+        const double invK = a.invK;
+        const double mean = sm * invK;
+        const float mu = (float)mean;
+        const float rstd = rsqrtf((float)var_f64(sq * invK, mean) + 1e-5f);
+        float4 accs[3];
+#pragma unroll
+        for (int which = 0; which < 3; ++which) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int pi = 0; pi < PMAX; ++pi)
+                if (rsel + pi * RPI < a.S) {
+                    acc.x += sl[which][pi].x; acc.y += sl[which][pi].y;
+                    acc.z += sl[which][pi].z; acc.w += sl[which][pi].w;
+                }
+#pragma unroll
+            for (int o = LPR; o < 64; o <<= 1) {
+                acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o);
+                acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
+            }
+            accs[which] = acc;
+        }
+        if (rsel == 0) {
+            float4 r[3];
+#pragma unroll
+            for (int which = 0; which < 3; ++which) {
+                const float4 acc = accs[which];
+                if (a.mode == 0) {
+                    r[which] = make_float4(rstd * (acc.x - mu * cc[which].x) + bb[which].x,
+                                           rstd * (acc.y - mu * cc[which].y) + bb[which].y,
+                                           rstd * (acc.z - mu * cc[which].z) + bb[which].z,
+                                           rstd * (acc.w - mu * cc[which].w) + bb[which].w);
+                } else {
+                    r[which] = make_float4(acc.x + bb[which].x, acc.y + bb[which].y, acc.z + bb[which].z, acc.w + bb[which].w);
+                }
+            }
+            if (a.mode == 1) {
+                // q_norm / k_norm: LayerNorm over the hd values of this head (eps 1e-6, affine)
+#pragma unroll
+                for (int which = 0; which < 2; ++which) {
+                    float4 v4 = lane_on ? r[which] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float sm1 = v4.x + v4.y + v4.z + v4.w;
+#pragma unroll
+                    for (int o = 1; o < LPR; o <<= 1) sm1 += __shfl_xor(sm1, o);
+                    const float mean = sm1 * (1.0f / HD);
+                    float4 dv = make_float4(v4.x - mean, v4.y - mean, v4.z - mean, v4.w - mean);
+                    float sq1 = lane_on ? dv.x * dv.x + dv.y * dv.y + dv.z * dv.z + dv.w * dv.w : 0.f;
+#pragma unroll
+                    for (int o = 1; o < LPR; o <<= 1) sq1 += __shfl_xor(sq1, o);
+                    const float rs = rsqrtf(sq1 * (1.0f / HD) + 1e-6f);
+                    const float4 gw = *(const float4*)((which == 0 ? a.qn_w : a.kn_w) + sub * 4);
+                    const float4 gb = *(const float4*)((which == 0 ? a.qn_b : a.kn_b) + sub * 4);
+                    r[which] = make_float4(dv.x * rs * gw.x + gb.x, dv.y * rs * gw.y + gb.y, dv.z * rs * gw.z + gb.z,
+                                           dv.w * rs * gw.w + gb.w);
+                }
+            }
+            if (lane_on) {
+#pragma unroll
+                for (int which = 0; which < 3; ++which) *(float4*)(&qkv_s[which][sub * 4]) = r[which];
+                // present = (k, v) of this step -> cache row T-1 (mingpt.py:77 / rar.py:96-107)
+                *(float4*)(Kc + (long long)(T - 1) * HD + sub * 4) = r[1];
+                *(float4*)(Vc + (long long)(T - 1) * HD + sub * 4) = r[2];
+            }
+        }
+    }
+    __syncthreads();
+    const float4 qM = *(const float4*)(&qkv_s[0][m16 * 4]), qT = *(const float4*)(&qkv_s[0][64 + t4 * 4]);
+    const float4 knM = *(const float4*)(&qkv_s[1][m16 * 4]), knT = *(const float4*)(&qkv_s[1][64 + t4 * 4]);
+    const float4 vnM = *(const float4*)(&qkv_s[2][m16 * 4]), vnT = *(const float4*)(&qkv_s[2][64 + t4 * 4]);
+    __builtin_amdgcn_sched_barrier(0);
+
+    float m = -INFINITY, l = 0.f;
+    float4 accM = make_float4(0.f, 0.f, 0.f, 0.f), accT = accM;
+#define WMAR_A80_CHUNK(KM, KT, VM, VT, C0)                                               \
+    {                                                                                    \
+        const int tt = (C0) * ROWS + 4 * ut + g16;                                       \
+        if (tt >= T - 1) { KT = knT; VT = vnT; }                                         \
+        float pt = KT.x * qT.x + KT.y * qT.y + KT.z * qT.z + KT.w * qT.w;                \
+        pt += __shfl_xor(pt, 1); pt += __shfl_xor(pt, 2);     /* the row's 16 tail floats */ \
+        float sc[4];                                                                     \
+        float cm = -INFINITY;                                                            \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                  \
+            const int t = (C0) * ROWS + 4 * u + g16;                                     \
+            if (t >= T - 1) { KM[u] = knM; VM[u] = vnM; }                                \
+            float p = KM[u].x * qM.x + KM[u].y * qM.y + KM[u].z * qM.z + KM[u].w * qM.w; \
+            p += __shfl_xor(p, 1); p += __shfl_xor(p, 2); p += __shfl_xor(p, 4); p += __shfl_xor(p, 8); \
+            p += __shfl(pt, (lane & 48) + 4 * u);             /* tail partial of row 4u + g16: quad u of this 16-lane row */ \
+            p = (t < T) ? p * a.scale : -INFINITY;                                       \
+            sc[u] = p;                                                                   \
+            cm = fmaxf(cm, p);                                                           \
+        }                                                                                \
+        cm = fmaxf(cm, __shfl_xor(cm, 16)); cm = fmaxf(cm, __shfl_xor(cm, 32));          \
+        const float mn = fmaxf(m, cm);                                                   \
+        const float rs = __expf(m - mn);       /* 0 on the first chunk (m = -inf) */     \
+        l *= rs; accM.x *= rs; accM.y *= rs; accM.z *= rs; accM.w *= rs;                 \
+        accT.x *= rs; accT.y *= rs; accT.z *= rs; accT.w *= rs;                          \
+        float e4[4];                                                                     \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                  \
+            const float e = __expf(sc[u] - mn);                                          \
+            e4[u] = e;                                                                   \
+            l += e;                                                                      \
+            accM.x += e * VM[u].x; accM.y += e * VM[u].y; accM.z += e * VM[u].z; accM.w += e * VM[u].w; \
+        }                                                                                \
+        /* the tail lane's row is row 4 ut + g16: its weight is this lane's own e4[ut] */ \
+        const float et = ut == 0 ? e4[0] : (ut == 1 ? e4[1] : (ut == 2 ? e4[2] : e4[3])); \
+        accT.x += et * VT.x; accT.y += et * VT.y; accT.z += et * VT.z; accT.w += et * VT.w; \
+        m = mn;                                                                          \
+    }
+    // refills are UNCONDITIONAL (clamped rows): see k_attn_decode
+    WMAR_A80_LOAD(kmB, ktB, vmB, vtB, w + NWA)
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c = w; c < nchunk; c += 2 * NWA) {
+        WMAR_A80_CHUNK(kmA, ktA, vmA, vtA, c)
+        __builtin_amdgcn_sched_barrier(0);
+        WMAR_A80_LOAD(kmA, ktA, vmA, vtA, c + 2 * NWA)
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + NWA < nchunk) { WMAR_A80_CHUNK(kmB, ktB, vmB, vtB, c + NWA) }
+        __builtin_amdgcn_sched_barrier(0);
+        WMAR_A80_LOAD(kmB, ktB, vmB, vtB, c + 3 * NWA)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef WMAR_A80_LOAD
+#undef WMAR_A80_CHUNK
+    // l counts every row once per lane of its group: fold the four row groups; accM likewise; accT over the 16 quads
+    l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+        accM.x += __shfl_xor(accM.x, o); accM.y += __shfl_xor(accM.y, o); accM.z += __shfl_xor(accM.z, o); accM.w += __shfl_xor(accM.w, o);
+    }
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) {
+        accT.x += __shfl_xor(accT.x, o); accT.y += __shfl_xor(accT.y, o); accT.z += __shfl_xor(accT.z, o); accT.w += __shfl_xor(accT.w, o);
+    }
+    if (lane < 16) *(float4*)(&part[w][lane * 4]) = accM;
+    if (lane < 4) *(float4*)(&part[w][64 + lane * 4]) = accT;
+    if (lane == 0) { part[w][HD] = m; part[w][HD + 1] = l; }
+    __syncthreads();
+    if (w == 0 && lane < LPRA) {
+        float M = part[0][HD];
+#pragma unroll
+        for (int i = 1; i < NWA; ++i) M = fmaxf(M, part[i][HD]);
+        float L = 0.f;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < NWA; ++i) {
+            const float f = __expf(part[i][HD] - M);   // waves without rows: exp(-inf) = 0
+            const float4 pa = *(const float4*)(&part[i][lane * 4]);
+            L += part[i][HD + 1] * f;
+            o.x += pa.x * f; o.y += pa.y * f; o.z += pa.z * f; o.w += pa.w * f;
+        }
+        const float inv = 1.0f / L;
+        const int k = h * HD + lane * 4;
+        const int kb = k >> 3, hf = (k >> 2) & 1;
+        const int mt = b >> 5;
+        const float4 yv = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+        if (a.yq) bx_store_planes4(a.yq, a.MT, kb, hf, mt, b & 31, yv);
+        else a.y[((long long)kb * a.MT + mt) * 64 + (b & 31) + 32 * hf] = yv;
+    }
+}
+
 }  // namespace wmar

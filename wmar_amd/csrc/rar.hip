@@ -496,6 +496,7 @@ struct RarPlan {
     // words of one k_resid_mod launch site at THIS plan's row count: [chunks][32 MT][2]; the sites are packed at this size, so the
     // poison memset of a position covers exactly what the launches poll
     size_t site_words() const { const int kpw = KBD <= 256 ? 1 : 4; return (size_t)((KBD + 4 * kpw - 1) / (4 * kpw)) * MT * 32 * 2; }
+    static bool att80() { static int v = -1; if (v < 0) { const char* e = getenv("WMAR_RAR_ATT80"); v = (e && atoi(e) == 0) ? 0 : 1; } return v != 0; }
     bool fc1_bx() const {
         return bx && g->bx_fc1
 #ifdef WMAR_DEV_KNOBS
@@ -539,7 +540,14 @@ struct RarPlan {
             case 32: WMAR_RAR_ATT(32) break;
             case 48: WMAR_RAR_ATT(48) break;
             case 64: WMAR_RAR_ATT(64) break;
-            case 80: WMAR_RAR_ATT(80) break;
+            case 80:
+                // all 64 lanes busy (k_attn_decode80); WMAR_RAR_ATT80=0 at run time keeps the 20-of-32-lane form (A/B)
+                if (att80()) {
+                    if (nwa == 1) hipLaunchKernelGGL((k_attn_decode80<1>), grid, dim3(64), 0, st, t);
+                    else if (nwa == 4) hipLaunchKernelGGL((k_attn_decode80<4>), grid, dim3(256), 0, st, t);
+                    else hipLaunchKernelGGL((k_attn_decode80<2>), grid, dim3(128), 0, st, t);
+                } else { WMAR_RAR_ATT(80) }
+                break;
             case 88: WMAR_RAR_ATT(88) break;
             default: WMAR_RAR_ATT(128) break;
         }
