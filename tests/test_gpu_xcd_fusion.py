@@ -1,0 +1,71 @@
+"""The fused output projection + residual fold + LN2 statistics launch (k_bx_xr: split-K reduction behind an XCD-local L2 barrier) against
+the two-launch path (k_bx + k_resid_stats) it replaces, at production width (1536 x 24 heads, 64 rows).
+
+Both paths fold the same slabs in the same order; they differ only in how the LayerNorm statistics are chunked (16 chunks of 96 columns
+against 12 of 128), i.e. in the last bits of an fp64 sum: logits agree to fp32 rounding and the sampled tokens are identical.  The engine's
+status entry point reports clean flags (no barrier timeout, no block on a foreign XCD)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from wmar_amd.utils import synth  # noqa: E402
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from wmar_amd.utils import synth
+from wmar_amd.models.engine import GPTEngine
+cfg = synth.GPTConfig(vocab_size=16384, block_size=256, n_layer=4, n_head=24, n_embd=1536)
+eng = GPTEngine(cfg, synth.synth_gpt_state(cfg, seed=3, logit_scale=10.0), max_batch=64)
+print("PLAN", eng.plan_info(64)["proj"])
+seq = torch.randint(0, cfg.vocab_size, (64, 40), generator=torch.Generator().manual_seed(5)).cuda()
+out = [eng.decode_step(seq[:, t], t).cpu().numpy() for t in range(40)]
+q = torch.empty(64, 64, cfg.vocab_size).exponential_(1, generator=torch.Generator().manual_seed(7)).cuda()
+tok = eng.generate(torch.arange(64).cuda(), 64, q, 1.0, 250, 0.92, None, use_graph=True)
+np.savez(sys.argv[1], logits=np.stack(out), tokens=tok.cpu().numpy())
+"""
+
+
+def _run(tmp_path, name, env_extra):
+    out = tmp_path / f"{name}.npz"
+    env = dict(os.environ, **env_extra)
+    res = subprocess.run([sys.executable, "-c", _CHILD % REPO, str(out)], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    plan = [l for l in res.stdout.splitlines() if l.startswith("PLAN")][0]
+    return np.load(out), plan
+
+
+def test_fused_projection_matches_the_two_launch_path(tmp_path):
+    fused, plan_f = _run(tmp_path, "fused", {})
+    plain, plan_p = _run(tmp_path, "plain", {"WMAR_NO_XR": "1"})
+    assert "k_bx<1" in plan_p
+    if "k_bx_xr" not in plan_f:
+        pytest.skip("the block -> XCD grouping probe did not enable the fused launch on this device: " + plan_f)
+    d = np.abs(fused["logits"] - plain["logits"]).max()
+    assert d <= 2e-5, d
+    assert np.array_equal(fused["tokens"], plain["tokens"])
+
+
+def test_status_entry_point_and_phase_reset():
+    from wmar_amd.models.engine import GPTEngine
+    from wmar_amd import _lib
+    cfg = synth.GPTConfig(vocab_size=16384, block_size=64, n_layer=2, n_head=24, n_embd=1536)
+    eng = GPTEngine(cfg, synth.synth_gpt_state(cfg, seed=1, logit_scale=5.0), max_batch=64)
+    tok = torch.zeros(64, dtype=torch.int64, device="cuda")
+    for t in range(8):
+        eng.decode_step(tok, t)
+    _lib.check(eng._L.wmar_gpt_check(eng._h, _lib.stream_ptr(eng.device)))        # no timeout, no foreign XCD
+    # (-1, -1) returns the attention schedule to the automatic one after a manual setting
+    auto = eng.plan_info(8)["attn"]
+    eng.set_attention_phases(0, 0)
+    assert eng.plan_info(8)["attn"] != auto
+    eng.set_attention_phases(-1, -1)
+    assert eng.plan_info(8)["attn"] == auto
