@@ -127,6 +127,10 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
     __shared__ int sh_i[2];
     __shared__ float red_f[SAMP_WAVES];
     __shared__ int red_i[SAMP_WAVES];
+    // the noise row of rows that fit registers 16 values per thread (V <= 16384): requested in P0, parked here (64 KB: the
+    // workgroup owns its CU) and read back for the final race -- held in registers through the passes it cost 30 spilled VGPRs
+    // at the 128 the 1024-thread workgroup allows (round-3 review)
+    __shared__ float q_lds[(EPT > 0 && EPT <= 16) ? EPT * SAMP_THREADS : 1];
 
     const long long b = blockIdx.x;
     const long long V = a.V;
@@ -171,6 +175,10 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
             if (PLAIN) qpre[i] = q[v < V ? v : V - 1];
             else qpre[i] = v < V ? q[WMAR_SRC(v)] : 1.f;
         }
+    }
+#define WMAR_PARK_Q()                                                                        \
+    if (EPT > 0 && EPT <= 16) {                                                              \
+        _Pragma("unroll") for (int i = 0; i < QN; ++i) q_lds[tid + i * SAMP_THREADS] = qpre[i]; \
     }
     if (EPT > 0 && PLAIN) {
         constexpr int CH = EPT > 8 ? 8 : (EPT > 0 ? EPT : 1);        // 8 logits + 8 key words in flight beside the 16 noise values: no spills at 128 VGPRs
@@ -253,6 +261,8 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
             kmax = max(kmax, wmar_f32_key(xv));
         }
     }
+    WMAR_PARK_Q()            // each thread reads back its own words: no barrier needed
+#undef WMAR_PARK_Q
     kmax = block_max_u32(kmax, red);
     const float m = wmar_key_f32(kmax);
     const uint32_t NEG_INF_KEY = 0x007fffffu;  // wmar_f32_key(-inf)
@@ -416,7 +426,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 const long long v = tid + (long long)(c0 + j) * SAMP_THREADS;
-                if (EPT <= 16) qv[j] = qpre[(c0 + j) % QN];
+                if (EPT <= 16) qv[j] = q_lds[tid + ((c0 + j) % QN) * SAMP_THREADS];
                 else qv[j] = v < V ? q[WMAR_SRC(v)] : 1.f;
             }
 #pragma unroll
