@@ -9,7 +9,8 @@ ENGINES = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 PASSES = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 cfg = synth.TAMING_GPT
-sd = synth.synth_gpt_state(cfg, seed=0, logit_scale=10.0)
+# WMAR_FAST_WEIGHTS=1: weights drawn on the GPU (seconds instead of a minute; any weights do for this test)
+sd = synth.synth_gpt_state_fast(cfg, 0, "cuda", logit_scale=10.0) if os.environ.get("WMAR_FAST_WEIGHTS") else synth.synth_gpt_state(cfg, seed=0, logit_scale=10.0)
 g = torch.Generator().manual_seed(5)
 seq = torch.randint(0, cfg.vocab_size, (B, 256), generator=g).cuda()
 ref = None
