@@ -1,7 +1,7 @@
 """Chameleon-7B (BASELINE config 4) timing on one GPU: text->image token loop at batch B (3B sequences),
 then VQGAN-512 decode / re-encode / detect.  Synthetic bf16 weights."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("WMAR_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from wmar_amd.models.chameleon_wrapper import ChameleonARMMWrapper
 from wmar_amd.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy

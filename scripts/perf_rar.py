@@ -1,6 +1,6 @@
 """RAR-XL end-to-end timing on one GPU: sample (CFG, 256 steps) -> decode -> re-encode -> detect."""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("WMAR_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from wmar_amd.models.rar_wrapper import RarARMMWrapper
 from wmar_amd.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy

@@ -17,6 +17,19 @@ __device__ __forceinline__ float4 ld_nt(const float4* p) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// Output the NEXT kernel reads (QKV split-K pieces: 8.3 MB per launch, FC2 slabs, the hidden activation): a write-through store (sc1),
+// so the bytes leave the XCD's L2 while the kernel runs instead of in the write-back at its end, which the next kernel waits for
+// (guide: boundary + dirty bytes / 6 TB/s).  Round 4, same-box A/B over the 256-step loop: 4.140 -> 4.110 ms per step.  Same values,
+// only the cache policy differs; -DWMAR_PLAIN_STORES restores plain stores.  (Data a later phase of the SAME launch reads through the
+// L2 -- the slabs of k_bx_xr -- must stay plain: an sc1 store drops the line.)
+__device__ __forceinline__ void st_out(float4* p, const float4 v) {
+#ifndef WMAR_PLAIN_STORES
+    const f32x4 q = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(q) : "memory");
+#else
+    *p = v;
+#endif
+}
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 __device__ __forceinline__ float2 ld_nt2(const float2* p) {
     f32x2 v = __builtin_nontemporal_load((const f32x2*)p);
@@ -461,7 +474,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
                 bx_store_planes4(a.out_planes, a.MT, nt * 4 + g, lane >> 5, mt, lane & 31, make_float4(o[0], o[1], o[2], o[3]));
             } else {
                 float4* dst = a.out_packed + (long long)s * a.slab_stride + ((long long)(nt * 4 + g) * a.MT + mt) * 64 + lane;
-                *dst = make_float4(o[0], o[1], o[2], o[3]);
+                st_out(dst, make_float4(o[0], o[1], o[2], o[3]));
             }
         } else if (EPI == EPI_QKV) {
             if (m < a.B) {
@@ -693,7 +706,7 @@ static __global__ __launch_bounds__(256) void k_fc1x(Fc1xArgs a) {
         const float4 bb = *(const float4*)(a.bias + n);
         o[0] = gelu_erf(rs * (o[0] - mm * cc.x) + bb.x); o[1] = gelu_erf(rs * (o[1] - mm * cc.y) + bb.y);
         o[2] = gelu_erf(rs * (o[2] - mm * cc.z) + bb.z); o[3] = gelu_erf(rs * (o[3] - mm * cc.w) + bb.w);
-        a.out[((long long)(n >> 3) * 2 + (m >> 5)) * 64 + (m & 31) + 32 * ((n >> 2) & 1)] = make_float4(o[0], o[1], o[2], o[3]);
+        st_out(a.out + ((long long)(n >> 3) * 2 + (m >> 5)) * 64 + (m & 31) + 32 * ((n >> 2) & 1), make_float4(o[0], o[1], o[2], o[3]));
     }
 #ifdef WMAR_FX_TRACE
     if (a.trace && threadIdx.x == 0) {
@@ -949,8 +962,8 @@ __global__ __launch_bounds__(512) void k_qkvx(QkvxArgs a) {
     for (int i = 0; i < MTW; ++i)
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4)
-            a.out[(long long)s * a.out_stride + ((long long)(nt * 4 + q4) * MTW + i) * 64 + lane] =
-                make_float4(acc[i][q4 * 4 + 0], acc[i][q4 * 4 + 1], acc[i][q4 * 4 + 2], acc[i][q4 * 4 + 3]);
+            st_out(a.out + (long long)s * a.out_stride + ((long long)(nt * 4 + q4) * MTW + i) * 64 + lane,
+                   make_float4(acc[i][q4 * 4 + 0], acc[i][q4 * 4 + 1], acc[i][q4 * 4 + 2], acc[i][q4 * 4 + 3]));
     if (keeper) __syncthreads();
 #ifdef WMAR_QX_TRACE
     if (a.trace && lane == 0) {
@@ -1241,8 +1254,8 @@ __global__ __launch_bounds__(512) void k_qkvx_bx(QkvxArgs a) {
     for (int i = 0; i < MTW; ++i)
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4)
-            a.out[(long long)s * a.out_stride + ((long long)(nt * 4 + q4) * MTW + i) * 64 + lane] =
-                make_float4(acc[i][q4 * 4 + 0], acc[i][q4 * 4 + 1], acc[i][q4 * 4 + 2], acc[i][q4 * 4 + 3]);
+            st_out(a.out + (long long)s * a.out_stride + ((long long)(nt * 4 + q4) * MTW + i) * 64 + lane,
+                   make_float4(acc[i][q4 * 4 + 0], acc[i][q4 * 4 + 1], acc[i][q4 * 4 + 2], acc[i][q4 * 4 + 3]));
     if (keeper) __syncthreads();
 }
 
@@ -1369,7 +1382,7 @@ __global__ __launch_bounds__(256) void k_bx(BxArgs a) {
             v = make_float4(gelu_erf(v.x + bb.x), gelu_erf(v.y + bb.y), gelu_erf(v.z + bb.z), gelu_erf(v.w + bb.w));
             bx_store_planes4(a.outq, MTW, kb, hf, i, lane & 31, v);
         } else {
-            out[((long long)((grp * NT + t) * 4 + g) * MTW + i) * 64 + lane] = v;
+            st_out(out + ((long long)((grp * NT + t) * 4 + g) * MTW + i) * 64 + lane, v);
         }
     }
 }
