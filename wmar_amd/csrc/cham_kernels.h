@@ -506,11 +506,17 @@ __global__ __launch_bounds__(NWA * 64) void k_cham_attn(ChamAttnArgs a) {
     uint16_t* Vc = a.vcache + (((long long)m * a.Hkv + hk) * a.Tmax) * HD + sub * 8;
     const int nchunk = (T + ROWS - 1) / ROWS;
 
+// K/V rows stream once per step: non-temporal loads (see k_attn_decode; -DWMAR_ATT_PLAIN_KV restores plain loads)
+#ifndef WMAR_ATT_PLAIN_KV
+#define CA_KV_LD(P_) ([](const uint16_t* p_) { const u32x4 v_ = __builtin_nontemporal_load((const u32x4*)p_); return make_uint4(v_.x, v_.y, v_.z, v_.w); })(P_)
+#else
+#define CA_KV_LD(P_) (*(const uint4*)(P_))
+#endif
 #define CA_LOAD(KB_, VB_, C0)                                                             \
     _Pragma("unroll") for (int u = 0; u < CH; ++u) {                                      \
         const int t = min((C0) * ROWS + u * RPI + rsel, T - 1);                           \
-        KB_[u] = *(const uint4*)(Kc + (long long)t * HD);                                 \
-        VB_[u] = *(const uint4*)(Vc + (long long)t * HD);                                 \
+        KB_[u] = CA_KV_LD(Kc + (long long)t * HD);                                        \
+        VB_[u] = CA_KV_LD(Vc + (long long)t * HD);                                        \
     }
     uint4 kA[CH], vA[CH], kB[CH], vB[CH];
     if (w < nchunk) { CA_LOAD(kA, vA, w) }

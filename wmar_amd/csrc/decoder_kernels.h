@@ -1590,6 +1590,15 @@ static int launch_bx_xr(const BxrArgs& q, int N, hipStream_t st) {
 }
 
 // --------------------------------------------------------------------- decode attention
+// K/V rows are streamed once per step and the cache (9.7 GB at batch 64) is far larger than the L2s and the memory-side cache: they
+// are loaded NON-TEMPORALLY -- round 4, same-box A/B over the 256-step loop: 4.112 -> 3.98 ms per step (Taming), 3.948 -> 3.899 (RAR-XL):
+// with plain loads 100 MB of K/V per layer swept the slabs, pieces and activations of the neighbouring launches out of the L2s.
+// -DWMAR_ATT_PLAIN_KV restores plain loads.
+#ifndef WMAR_ATT_PLAIN_KV
+#define WMAR_KV_LD(P) ld_nt(P)
+#else
+#define WMAR_KV_LD(P) (*(P))
+#endif
 // One wave per (sequence, head).  K/V rows are hd floats; LPR = hd/4 lanes cover a row with
 // float4s and RPI = 64/LPR rows are read per wave-wide load (1 KiB, coalesced).
 struct AttnArgs {
@@ -1652,8 +1661,8 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
 #define WMAR_ATT_LOAD(KB, VB, C0)                                                        \
     _Pragma("unroll") for (int u = 0; u < CH; ++u) {                                     \
         const int t = min((C0) * ROWS + u * RPI + rsel, T - 1);                          \
-        KB[u] = *(const float4*)(Kc + (long long)t * HD);                                \
-        VB[u] = *(const float4*)(Vc + (long long)t * HD);                                \
+        KB[u] = WMAR_KV_LD((const float4*)(Kc + (long long)t * HD));                     \
+        VB[u] = WMAR_KV_LD((const float4*)(Vc + (long long)t * HD));                     \
     }
     float4 kA[CH], vA[CH], kB[CH], vB[CH];
     float4 q, knew, vnew;
@@ -1911,12 +1920,12 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode80(AttnArgs a) {
 #define WMAR_A80_LOAD(KM, KT, VM, VT, C0)                                                \
     _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                      \
         const int t = min((C0) * ROWS + 4 * u + g16, T - 1);                             \
-        KM[u] = *(const float4*)(Kmain + (long long)t * HD);                             \
-        VM[u] = *(const float4*)(Vmain + (long long)t * HD);                             \
+        KM[u] = WMAR_KV_LD((const float4*)(Kmain + (long long)t * HD));                  \
+        VM[u] = WMAR_KV_LD((const float4*)(Vmain + (long long)t * HD));                  \
     }                                                                                    \
     { const int t = min((C0) * ROWS + 4 * ut + g16, T - 1);                              \
-      KT = *(const float4*)(Ktail + (long long)t * HD);                                  \
-      VT = *(const float4*)(Vtail + (long long)t * HD); }
+      KT = WMAR_KV_LD((const float4*)(Ktail + (long long)t * HD));                       \
+      VT = WMAR_KV_LD((const float4*)(Vtail + (long long)t * HD)); }
     float4 kmA[4], vmA[4], ktA, vtA, kmB[4], vmB[4], ktB, vtB;
     // PF2: the wave's first TWO chunks are requested before the prologue (32 KiB in flight per wave: with 1 / 2 / 4 waves the
     // whole cache up to 64 / 128 / 256 rows streams while q/k/v are finished); otherwise one, the second from inside the loop.

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
 #pragma unroll
         for (int i = 0; i < QN; ++i) {
             const long long v = tid + (long long)i * SAMP_THREADS;
-            if (PLAIN) qpre[i] = q[v < V ? v : V - 1];
+            if (PLAIN) qpre[i] = __builtin_nontemporal_load(q + (v < V ? v : V - 1));      // 1 GB of noise per generation, read once
             else qpre[i] = v < V ? q[WMAR_SRC(v)] : 1.f;
         }
     }
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
             for (int j = 0; j < CH; ++j) {
                 const long long v = tid + (long long)(c0 + j) * SAMP_THREADS;
                 const long long vv = v < V ? v : V - 1;
-                lv[j] = lg[vv];
+                lv[j] = __builtin_nontemporal_load(lg + vv);
                 gw[j] = gp[vv >> 5];
             }
 #pragma unroll
