@@ -508,7 +508,7 @@ __global__ __launch_bounds__(NWA * 64) void k_cham_attn(ChamAttnArgs a) {
 
 // K/V rows stream once per step: non-temporal loads (see k_attn_decode; -DWMAR_ATT_PLAIN_KV restores plain loads)
 #ifndef WMAR_ATT_PLAIN_KV
-#define CA_KV_LD(P_) ([](const uint16_t* p_) { const u32x4 v_ = __builtin_nontemporal_load((const u32x4*)p_); return make_uint4(v_.x, v_.y, v_.z, v_.w); })(P_)
+#define CA_KV_LD(P_) ld_nt_u4((const uint4*)(P_))
 #else
 #define CA_KV_LD(P_) (*(const uint4*)(P_))
 #endif
