@@ -321,7 +321,11 @@ struct StepPlan {
         else if (nwa == 2) hipLaunchKernelGGL((k_attn_decode<HDV, 2, PF>), grid, dim3(128), 0, st, t);         \
         else hipLaunchKernelGGL((k_attn_decode<HDV, 4, PF>), grid, dim3(256), 0, st, t);
 #define WMAR_ATT_LAUNCH(HDV) if (pf2) { WMAR_ATT_LAUNCH2(HDV, true) } else { WMAR_ATT_LAUNCH2(HDV, false) }
-        const bool pf2 = false;    // re-measured with exact waits (round 3): +-1 % either way; kept for the 2- and 4-wave variants
+#ifdef WMAR_ATT_PF2
+        const bool pf2 = true;
+#else
+        const bool pf2 = false;    // re-measured with exact waits (round 3) and with non-temporal K/V loads (round 4): +-1 % either way
+#endif
         if (g->hd == 64) { WMAR_ATT_LAUNCH(64) }
         else if (g->hd == 32) { WMAR_ATT_LAUNCH(32) }
         else { WMAR_ATT_LAUNCH(128) }
