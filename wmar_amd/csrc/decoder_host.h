@@ -39,11 +39,16 @@ int copy_vec(Engine* g, float** dst, const float* src, size_t n, hipStream_t st)
     return WMAR_OK;
 }
 
-template <int MTW, int NW, int EPI, bool LN, int ABL = 0, int U = GEMM_STAGE, bool ROT = true>
+template <int MTW, int NW, int EPI, bool LN, int ABL = 0, int U = GEMM_STAGE, bool ROT = true, int NTW = 1>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
-    const int grid = a.NT * (a.MT / MTW) * a.S + a.n_hi;
-    const size_t lds = (size_t)NW * MTW * 16 * 64 * sizeof(float);
-    hipLaunchKernelGGL((k_gemm<MTW, NW, EPI, LN, ABL, U, ROT>), dim3((unsigned)grid), dim3(NW * 64), lds, st, a);
+    const int grid = NTW > 1 ? (a.NT / NTW) * (a.MT / MTW) : a.NT * (a.MT / MTW) * a.S + a.n_hi;
+    const size_t lds = (size_t)NW * MTW * NTW * 16 * 64 * sizeof(float);
+    if (NTW > 1 && (a.NT % NTW != 0 || a.S != 1 || a.n_hi != 0)) { set_error("k_gemm: %d column tiles per workgroup need S == 1 and NT %% %d == 0", NTW, NTW); return WMAR_EINVAL; }
+    if (lds > 64 * 1024) {      // more than the default dynamic LDS limit: opt in once per instantiation
+        static bool done = false;
+        if (!done) { (void)hipFuncSetAttribute((const void*)k_gemm<MTW, NW, EPI, LN, ABL, U, ROT, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+    }
+    hipLaunchKernelGGL((k_gemm<MTW, NW, EPI, LN, ABL, U, ROT, NTW>), dim3((unsigned)grid), dim3(NW * 64), lds, st, a);
     return launch_status("k_gemm");
 }
 

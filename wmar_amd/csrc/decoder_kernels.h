@@ -249,15 +249,22 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // grid = NT * (MT/MTW) * S workgroups of NW waves.  Each workgroup owns one 32-column
 // tile of the output for MTW row tiles and one K slice; its NW waves split that K slice
 // and reduce through LDS in a fixed order.
-template <int MTW, int NW, int EPI, bool LN, int ABL = 0, int U = GEMM_STAGE, bool ROT = true>
+// NTW > 1 (round 4): NTW adjacent column tiles per workgroup -- every activation fragment then feeds NTW weight fragments, i.e. the
+// workgroup pulls 1 / NTW as many activation bytes per weight byte through its CU (whole-K launches with thousands of column tiles --
+// the vocabulary head, RAR's adaLN GEMM -- were bound by exactly that: t ~ bytes per CU / 33 GB/s).  Host: S == 1,
+// n_hi == 0, NT % NTW == 0.
+template <int MTW, int NW, int EPI, bool LN, int ABL = 0, int U = GEMM_STAGE, bool ROT = true, int NTW = 1>
 __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [NW][MTW*16][64]
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [NW][NTW*MTW*16][64]
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int MG = a.MT / MTW;
     int bid = blockIdx.x;
     int nt, mg, s, S_t = a.S;
-    if (bid < a.NT * MG * a.S) {
+    if (NTW > 1) {                             // groups of NTW tiles; no K split across workgroups
+        const int NTG = a.NT / NTW;
+        nt = (bid % NTG) * NTW; mg = bid / NTG; s = 0;
+    } else if (bid < a.NT * MG * a.S) {
         nt = bid % a.NT; bid /= a.NT;
         mg = bid % MG;
         s = bid / MG;
@@ -284,24 +291,28 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
     unsigned long long tr0 = __builtin_amdgcn_s_memtime(), tr1 = 0, tr2 = 0;
 #endif
 
-    f32x16 acc[MTW];
+    f32x16 acc[NTW][MTW];
 #pragma unroll
-    for (int i = 0; i < MTW; ++i)
+    for (int t = 0; t < NTW; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.f;
 
     float mu[MTW], rstd[MTW];
     const float4* Wp = a.Wp + (long long)nt * a.KB * 64 + lane;
+    const long long wtile = (long long)a.KB * 64;           // next column tile
     const float4* Xp = a.Xp + (long long)mt0 * 64 + lane;
     const long long xstep = (long long)a.MT * 64;
 
     // Register double buffer: while the MFMAs of one stage (U k-blocks = 4U instructions per
     // row tile) run, the loads of the next stage are in flight.
-    float4 wA[U], wB[U], xA[U][MTW], xB[U][MTW];
+    float4 wA[U][NTW], wB[U][NTW], xA[U][MTW], xB[U][MTW];
 #define WMAR_LOAD(WBUF, XBUF, KB0)                                                              \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                            \
         const int kk = (KB0) + u;                                                               \
-        WBUF[u] = (ABL == 2) ? make_float4(1.f, 2.f, 3.f, (float)kk) : ld_nt(Wp + (long long)kk * 64); \
+        _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                        \
+            WBUF[u][t] = (ABL == 2) ? make_float4(1.f, 2.f, 3.f, (float)kk) : ld_nt(Wp + t * wtile + (long long)kk * 64); \
         _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
             XBUF[u][i] = (ABL == 1) ? make_float4(1.f, 2.f, 3.f, (float)kk) : Xp[(long long)kk * xstep + i * 64]; \
     }
@@ -315,16 +326,20 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
     {                                                                                           \
         if (ABL == 3) {                                                                         \
             _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                    \
-                acc[i][0] += WV.x * XV[i].x + WV.y * XV[i].y + WV.z * XV[i].z + WV.w * XV[i].w; \
+                acc[0][i][0] += WV[0].x * XV[i].x + WV[0].y * XV[i].y + WV[0].z * XV[i].z + WV[0].w * XV[i].w; \
         } else {                                                                                \
+        _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                        \
         _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV.x, XV[i].x, acc[i], 0, 0, 0);      \
+            acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV[t].x, XV[i].x, acc[t][i], 0, 0, 0); \
+        _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                        \
         _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV.y, XV[i].y, acc[i], 0, 0, 0);      \
+            acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV[t].y, XV[i].y, acc[t][i], 0, 0, 0); \
+        _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                        \
         _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV.z, XV[i].z, acc[i], 0, 0, 0);      \
+            acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV[t].z, XV[i].z, acc[t][i], 0, 0, 0); \
+        _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                        \
         _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                        \
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV.w, XV[i].w, acc[i], 0, 0, 0);      \
+            acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WV[t].w, XV[i].w, acc[t][i], 0, 0, 0); \
         }                                                                                       \
     }
 // the normalisation of k-block u+1 is issued ahead of the MFMAs of k-block u (VALU under MFMA),
@@ -361,11 +376,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
         // keeps the matrix pipe idle for as long as the batch takes to issue (~30 cycles per 1 KiB load); one load fits in the
         // 64-cycle shadow of an MFMA
 #define WMAR_INTERLEAVE()                                                                          \
-        _Pragma("unroll") for (int i_ = 0; i_ < U * (1 + MTW); ++i_) {                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < U * (NTW + MTW); ++i_) {                          \
             __builtin_amdgcn_sched_group_barrier(0x008, WMAR_GEMM_INTERLEAVE, 0);                  \
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                     \
         }                                                                                          \
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * U * MTW - WMAR_GEMM_INTERLEAVE * U * (1 + MTW), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * U * MTW * NTW - WMAR_GEMM_INTERLEAVE * U * (NTW + MTW), 0);
         for (int it = 0; it < nfull; ++it) {
             WMAR_LOAD(wB, xB, WMAR_STAGE_KB(2 * it + 1))
             WMAR_MMA(wA, xA)
@@ -402,14 +417,14 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (u < nt_) {             // wave-uniform: only the blocks that exist are fetched
-                wA[u] = ld_nt(Wp + (long long)(kb + u) * 64);
+                _Pragma("unroll") for (int t = 0; t < NTW; ++t) wA[u][t] = ld_nt(Wp + t * wtile + (long long)(kb + u) * 64);
 #pragma unroll
                 for (int i = 0; i < MTW; ++i) xA[u][i] = Xp[(long long)(kb + u) * xstep + i * 64];
             }
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (U + u < nt_) {
-                wB[u] = ld_nt(Wp + (long long)(kb + U + u) * 64);
+                _Pragma("unroll") for (int t = 0; t < NTW; ++t) wB[u][t] = ld_nt(Wp + t * wtile + (long long)(kb + U + u) * 64);
 #pragma unroll
                 for (int i = 0; i < MTW; ++i) xB[u][i] = Xp[(long long)(kb + U + u) * xstep + i * 64];
             }
@@ -435,19 +450,23 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
     // adjacent) and the reducing wave reads one float4 per partner -- a quarter of the LDS instructions of a dword layout
     float4* smem4 = reinterpret_cast<float4*>(smem);
 #pragma unroll
-    for (int i = 0; i < MTW; ++i)
+    for (int t = 0; t < NTW; ++t)
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4)
-            smem4[((long long)w * (MTW * 4) + i * 4 + g4) * 64 + lane] =
-                make_float4(acc[i][g4 * 4 + 0], acc[i][g4 * 4 + 1], acc[i][g4 * 4 + 2], acc[i][g4 * 4 + 3]);
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                smem4[((long long)w * (NTW * MTW * 4) + (t * MTW + i) * 4 + g4) * 64 + lane] =
+                    make_float4(acc[t][i][g4 * 4 + 0], acc[t][i][g4 * 4 + 1], acc[t][i][g4 * 4 + 2], acc[t][i][g4 * 4 + 3]);
     __syncthreads();
 
-    for (int grp = w; grp < MTW * 4; grp += NW) {
-        const int i = grp >> 2, g = grp & 3;
+    const int nt_first = nt;
+    for (int grp = w; grp < NTW * MTW * 4; grp += NW) {
+        const int t_ = grp / (MTW * 4), i = (grp >> 2) % MTW, g = grp & 3;
+        nt = nt_first + t_;
         float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ww = 0; ww < NW; ++ww) {
-            const float4 t = smem4[((long long)ww * (MTW * 4) + i * 4 + g) * 64 + lane];
+            const float4 t = smem4[((long long)ww * (NTW * MTW * 4) + (t_ * MTW + i) * 4 + g) * 64 + lane];
             o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
         }
         const int mt = mt0 + i;

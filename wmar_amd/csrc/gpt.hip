@@ -240,6 +240,7 @@ struct StepPlan {
     // the predicates the launches below use (wmar_gpt_plan_info reports from the same ones)
     bool qkv_bx() const { return S_qx > 0 && MT == 2 && g->layers[0].wqkvx_bx && !g->no_bx && !g->no_bx_qkv; }
     bool fc1_x() const { return MT == 2 && g->layers[0].wfc1x16; }
+    static bool head_narrow() { static int v = -1; if (v < 0) v = getenv("WMAR_HEAD_NARROW") ? 1 : 0; return v != 0; }   // A/B: the two-launch 32-column head
     int split_for(int NT, int KB) const { return pick_split(MT % 2 == 0 ? NT * (MT / 2) : NT * MT, KB, 4); }
     GemmArgs base() const {
         GemmArgs a{};
@@ -400,11 +401,18 @@ struct StepPlan {
         h.Wp = g->whead; h.Xp = xcur; h.KB = KBD; h.NT = g->V / 32;
         h.bias = g->bhead; h.c1 = g->chead; h.logits = io.logits; h.V = g->V;
         g->span_begin(WMAR_T_HEAD, st);
+        int rc = WMAR_OK;
+        if (MT == 2 && h.NT % 2 == 0 && h.NT / 2 <= 512 && !head_narrow()) {
+            // 64 rows: TWO column tiles per workgroup (round 4) -- the launch was bound by the bytes a CU pulls (393 KB of activation
+            // beside 196 KB of weights per 32-column workgroup, two workgroups per CU: 42 us for 100 MB of weights); every activation
+            // fragment now feeds two weight fragments, one launch of V / 64 workgroups
+            h.S = 1;
+            rc = launch_gemm<2, 4, EPI_LOGITS, true, 0, GEMM_STAGE, true, 2>(h, st);
+        } else {
         // at most one workgroup per CU per launch: two workgroups on a CU share its MFMA pipes and L1 fill path, so 512 column
         // tiles run faster as two launches of 256 than as one of 512 (measured 56 us -> see DESIGN.md section 6)
         const int MG = (MT % 2 == 0) ? MT / 2 : MT;
         const int per = 256 / MG > 0 ? 256 / MG : 1;
-        int rc = WMAR_OK;
         const int NTall = h.NT;
         for (int nt0 = 0; nt0 < NTall && rc == WMAR_OK; nt0 += per) {
             GemmArgs p = h;
@@ -414,6 +422,7 @@ struct StepPlan {
             p.c1 = h.c1 + (long long)nt0 * 32;
             p.logits = h.logits + (long long)nt0 * 32;
             rc = gemm_dispatch<EPI_LOGITS, true>(p, false, st);
+        }
         }
         g->span_end(st);
         return rc;

@@ -464,6 +464,8 @@ struct RarPlan {
         a.Wp = g->wada; a.Xp = g->sc; a.KB = KBD; a.NT = (int)(g->Ntot / 32); a.bias = g->bada;
         a.out_packed = (float4*)g->mod; a.slab_stride = 0;        // packed [Ntot/8][MTc][64]: read like an activation by k_modulate / k_resid_mod
         if (shared_u) { a.MT = MTc; a.B = Bhalf; }
+        // (round 4: four column tiles per workgroup -- a quarter of the activation re-reads -- is 0.4 % SLOWER per step: at 1 wave per SIMD
+        // the fp32-MFMA-bound launch, 259 us at peak, loses more latency hiding than the bytes buy)
         return gemm_dispatch<EPI_PACKED, false>(a, false, st);
     }
     int modulate(const float* gamma, const float* beta, long long off_shift, long long off_scale, u32x4* planes = nullptr) {
