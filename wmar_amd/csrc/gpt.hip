@@ -633,10 +633,8 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
         // share an XCC id and that the eight groups land on eight different XCDs (three launches: the id a group gets rotates with
         // the launches before it, the grouping must not).  Anything else keeps the two-launch path.
         g->no_xr = getenv("WMAR_NO_XR") != nullptr;
-        unsigned* probe = g->xsync + 8 * 64 + 16;      // scratch behind the fail words is too small: use a temporary
         unsigned* tmp = nullptr;
         bool ok = hipMalloc(&tmp, 192 * 4) == hipSuccess;
-        (void)probe;
         for (int rep = 0; rep < 3 && ok; ++rep) {
             unsigned h[192];
             hipLaunchKernelGGL(k_xcc_probe, dim3(192), dim3(256), 0, st, tmp);
