@@ -115,12 +115,11 @@ def main():
         else:
             model = ChameleonARMMWrapper(args.modelpath, seed, device=device, max_batch=min(args.batch_size, 16))
     model.noise_device = args.noise_device
+    # Patch model: enc and/or dec (the reference's own calls, generate.py:327-332; all three tokenizers expose the handles)
     if args.encoder_ft_ckpt is not None and args.encoder_ft_ckpt != "none":
-        assert args.model == "taming", "delta checkpoints are wired for the Taming VQGAN only"
-        update_weights(model, "encoder", args.encoder_ft_ckpt)
+        update_weights(model.get_image_tokenizer().encoder, args.encoder_ft_ckpt)
     if args.decoder_ft_ckpt is not None and args.decoder_ft_ckpt != "none":
-        assert args.model == "taming", "delta checkpoints are wired for the Taming VQGAN only"
-        update_weights(model, "decoder", args.decoder_ft_ckpt)
+        update_weights(model.get_image_tokenizer().decoder, args.decoder_ft_ckpt)
 
     if ".txt" in args.conditioning:      # file with prompts (Chameleon): (index, prompt) tuples
         with open(args.conditioning, "r") as f:

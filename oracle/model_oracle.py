@@ -65,6 +65,42 @@ def gpt_step(sd: Dict[str, T], n_head: int, idx: T, past_k, past_v, past_length:
     return logits, new_k, new_v
 
 
+@torch.no_grad()
+def gpt_prefix(sd: Dict[str, T], n_head: int, idx: T, positions=None) -> T:
+    """GPT.forward_with_past on a whole prefix with `past=None`: the causally masked branch of
+    CausalSelfAttention.forward (deps/taming/modules/transformer/mingpt.py:69-95, mask :84-85) under
+    forward_with_past :183-214 (position embeddings `pos_emb[:, :T]`, :199).  Mathematically the logits the
+    incremental loop (`gpt_step`) produces at every position of a teacher-forced sequence, in ONE pass: what
+    makes the full 48-layer model checkable in seconds on a CPU.
+
+    idx [B,T] int64 -> logits [B, len(positions), V] (all T positions when `positions` is None)."""
+    B, Tn = idx.shape
+    x = sd["tok_emb.weight"][idx] + sd["pos_emb"][:, :Tn]                      # :186-199
+    d = x.shape[-1]
+    hd = d // n_head
+    mask = torch.tril(torch.ones(Tn, Tn, dtype=torch.bool))
+    i = 0
+    while f"blocks.{i}.ln1.weight" in sd:
+        p = f"blocks.{i}."
+        h = F.layer_norm(x, (d,), sd[p + "ln1.weight"], sd[p + "ln1.bias"], 1e-5)
+        k = F.linear(h, sd[p + "attn.key.weight"], sd[p + "attn.key.bias"]).view(B, Tn, n_head, hd).transpose(1, 2)
+        q = F.linear(h, sd[p + "attn.query.weight"], sd[p + "attn.query.bias"]).view(B, Tn, n_head, hd).transpose(1, 2)
+        v = F.linear(h, sd[p + "attn.value.weight"], sd[p + "attn.value.bias"]).view(B, Tn, n_head, hd).transpose(1, 2)
+        att = (q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(hd))
+        att = att.masked_fill(~mask, float("-inf"))
+        att = F.softmax(att, dim=-1)
+        y = (att @ v).transpose(1, 2).contiguous().view(B, Tn, d)
+        x = x + F.linear(y, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+        h2 = F.layer_norm(x, (d,), sd[p + "ln2.weight"], sd[p + "ln2.bias"], 1e-5)
+        h2 = F.gelu(F.linear(h2, sd[p + "mlp.0.weight"], sd[p + "mlp.0.bias"]))
+        x = x + F.linear(h2, sd[p + "mlp.2.weight"], sd[p + "mlp.2.bias"])
+        i += 1
+    if positions is not None:
+        x = x[:, list(positions)]
+    x = F.layer_norm(x, (d,), sd["ln_f.weight"], sd["ln_f.bias"], 1e-5)
+    return F.linear(x, sd["head.weight"])
+
+
 def default_q_source(step: int, B: int, V: int) -> T:
     """The noise torch.multinomial(probs, 1) draws: one [B,V] Exp(1) tensor per step
     from the default CPU generator."""

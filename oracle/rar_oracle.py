@@ -82,9 +82,10 @@ def default_q_source(step, B, V):
 def generate(sd: Dict[str, T], cfg, condition: T, guidance_scale=4.0, guidance_scale_pow=0.0,
              randomize_temperature=1.0, key: Optional[W.KeyParams] = None, delta: float = 0.0,
              q_source: Callable = default_q_source, record=None, draw_drop_mask: bool = True,
-             sampler: Optional[Callable] = None) -> T:
+             sampler: Optional[Callable] = None, max_steps: Optional[int] = None) -> T:
     """RAR.generate (rar.py:408-459) with classifier-free guidance and the logit processor.
-    condition int64 [B] class ids.  Returns int64 [B, image_seq_len]."""
+    condition int64 [B] class ids.  Returns int64 [B, image_seq_len].
+    max_steps (tests at full depth): stop after that many tokens -- the guidance schedule still spans image_seq_len."""
     B = condition.shape[0]
     V, L = cfg.codebook_size, cfg.image_seq_len
     if draw_drop_mask:
@@ -101,7 +102,7 @@ def generate(sd: Dict[str, T], cfg, condition: T, guidance_scale=4.0, guidance_s
     _, kc, vc = rar_position(sd, cfg, cls, cond_emb, 0, None, None)
     ids = torch.zeros(B, 0, dtype=torch.long)
     tok_emb = cond_emb                                                      # position 1 holds the condition token
-    for step in range(L):
+    for step in range(L if max_steps is None else min(L, max_steps)):
         logits, kc, vc = rar_position(sd, cfg, tok_emb, cond_emb, step + 1, kc, vc)
         cl, ul = logits[:B], logits[B:]
         if guidance_scale != 0:
@@ -120,7 +121,7 @@ def generate(sd: Dict[str, T], cfg, condition: T, guidance_scale=4.0, guidance_s
         q = q_source(step, B, V)
         tok = W.sample_rows(lg, q.numpy(), randomize_temperature, None, None)
         if record is not None:
-            record.append(dict(cond_logits=cl.numpy().copy(), uncond_logits=ul.numpy().copy(), q=q.numpy().copy(), tok=tok.copy()))
+            record.append(dict(cond_logits=cl.numpy().copy(), uncond_logits=ul.numpy().copy(), biased=np.array(lg), q=q.numpy().copy(), tok=tok.copy()))
         t = torch.from_numpy(tok)
         ids = torch.cat([ids, t.view(-1, 1)], dim=1)
         tok_emb = sd["embeddings.weight"][torch.cat([t, t])]

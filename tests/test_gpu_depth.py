@@ -1,0 +1,166 @@
+"""Parity at FULL DEPTH: the 48-layer Taming GPT (1.41 G parameters) and the 32-layer RAR-XL, engine against the CPU oracle.
+
+The production-width fixtures (test_gpu_prod_shapes.py) run 2 layers; what they cannot see is the growth of the bf16x6 / split-K
+summation-order error over 48 residual blocks and the weight-pack offsets of the layers >= 2.  Here:
+
+  * Taming: (a) teacher-forced logits against ONE causally masked pass of the oracle (`model_oracle.gpt_prefix` =
+    GPT.forward_with_past with past=None, mingpt.py:183-214 + the masked attention :69-95 -- the reference's own prefix path;
+    tests/test_oracle_golden.py pins it to the incremental path): 64 rows (the benchmark's batch: k_qkvx_bx, k_bx_xr, k_fc1x and
+    their per-layer packed weights) at positions 0, 1, 39, and 8 rows (the small-batch kernels, 2 / 4 attention waves) at
+    positions 113, 255 (long caches); the arg-max of every row equal;
+    (b) a 64-row x 48-step watermarked sampling loop (greenlist delta 2, top-k 250, top-p 0.92), graph and eager, token for
+    token against `model_oracle.sample_with_past` (mingpt.py:326-368) on the same noise.
+  * RAR-XL: 64 conditions under guidance (128 rows, the benchmark's batch), the first 12 tokens of RAR.generate
+    (rar.py:408-459) against `rar_oracle.generate`, and the logits of those positions.
+
+Tolerance: the 2-layer fixtures agree to 4e-5 with a 5e-4 gate.  Every block adds its own rounding to the residual stream and
+LayerNorm renormalises, so the error grows roughly with sqrt(depth) .. depth; the gate is 2e-3 absolute on logits whose standard
+deviation is ~8 (logit_scale 10) -- 4 x the 2-layer gate, far below anything that moves a sampled token -- and the measured
+maximum is printed (DESIGN.md section 4 records it).
+A sampled token may differ from the oracle's only where the two leading candidates of the race argmax(p/q) are closer than the
+logit tolerance (the test then stops comparing that row); at most one such row is accepted."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import model_oracle as M  # noqa: E402
+from oracle import rar_oracle as R  # noqa: E402
+from tests.test_gpu_watermark import _wm  # noqa: E402
+from wmar_amd.utils import synth  # noqa: E402
+
+ATOL_DEPTH = 2e-3
+
+
+def _host(sd):
+    return {k: v.detach().to("cpu", torch.float32) for k, v in sd.items()}
+
+
+@pytest.fixture(scope="module")
+def gpt48():
+    from wmar_amd.models.engine import GPTEngine
+    cfg = synth.TAMING_GPT
+    assert cfg.n_layer == 48 and cfg.n_embd == 1536
+    sd_dev = synth.synth_gpt_state_fast(cfg, seed=3, device="cuda", logit_scale=10.0)
+    eng = GPTEngine(cfg, sd_dev, max_batch=64)
+    sd = _host(sd_dev)          # the oracle's copy, moved to the host once
+    del sd_dev
+    torch.cuda.empty_cache()
+    return eng, sd
+
+
+def test_taming_48_layers_teacher_forced_logits(gpt48):
+    eng, sd = gpt48
+    cfg = synth.TAMING_GPT
+    rs = np.random.RandomState(48)
+    for rows, T, positions in ((64, 40, [0, 1, 39]), (8, 256, [113, 255])):
+        seq = torch.from_numpy(rs.randint(0, cfg.vocab_size, size=(rows, T)).astype(np.int64))
+        t0 = time.perf_counter()
+        ref = M.gpt_prefix(sd, cfg.n_head, seq, positions).numpy()            # [rows, len(positions), V]
+        t_cpu = time.perf_counter() - t0
+        seq_d = seq.cuda()
+        got = {}
+        for t in range(T):
+            lg = eng.decode_step(seq_d[:, t], t)
+            if t in positions:
+                got[t] = lg.cpu().numpy()
+        worst = 0.0
+        for i, t in enumerate(positions):
+            d = float(np.abs(got[t] - ref[:, i]).max())
+            worst = max(worst, d)
+            assert d < ATOL_DEPTH, (rows, t, d)
+            am, ram = got[t].argmax(-1), ref[:, i].argmax(-1)
+            for b in np.nonzero(am != ram)[0]:       # an arg-max may only move between two logits closer than the tolerance
+                assert abs(ref[b, i, am[b]] - ref[b, i, ram[b]]) < 2 * ATOL_DEPTH, (rows, t, b)
+        print(f"48 layers, {rows} rows: max |dlogit| {worst:.2e} at positions {positions} x 16384 logits (logit std {ref.std():.2f}); "
+              f"oracle prefix pass {t_cpu:.1f} s")
+
+
+def _compare_tokens(got, ref, record, tol):
+    """token-for-token; a row may leave the oracle's path only at a race closer than `tol` in (biased logit - log q)."""
+    near = 0
+    for b in range(ref.shape[0]):
+        bad = np.nonzero(got[b] != ref[b])[0]
+        if bad.size == 0:
+            continue
+        n = int(bad[0])
+        lg, q = record[n]["biased"][b].astype(np.float64) / 1.0, record[n]["q"][b].astype(np.float64)
+        race = lg - np.log(q)
+        assert abs(race[got[b, n]] - race[ref[b, n]]) < tol, f"row {b} step {n}: tokens {got[b, n]} / {ref[b, n]} are not a near tie"
+        near += 1
+    return near
+
+
+def test_taming_48_layers_watermarked_loop_tokens(gpt48, kat, key_factory):
+    eng, sd = gpt48
+    cfg = synth.TAMING_GPT
+    wm = _wm(kat["keys"]["taming"])
+    key = key_factory(kat["keys"]["taming"])
+    B, steps = 64, 48
+    cond = torch.tensor([(i * 37 + 3) % 1000 for i in range(B)])
+    g = torch.Generator().manual_seed(4848)
+    q = torch.empty(steps, B, cfg.vocab_size).exponential_(1, generator=g)
+    rec = []
+    t0 = time.perf_counter()
+    ref = M.sample_with_past(sd, cfg.n_head, cond.view(-1, 1), steps, 1.0, 250, 0.92, key, 2.0,
+                             q_source=lambda n, b, v: q[n], record=rec).numpy()
+    t_cpu = time.perf_counter() - t0
+    qd = q.cuda()
+    for graph in (True, False):
+        got = eng.generate(cond.cuda(), steps, qd, 1.0, 250, 0.92, wm.wm_ctx(), use_graph=graph).cpu().numpy()
+        near = _compare_tokens(got, ref, rec, 4 * ATOL_DEPTH)
+        assert near <= 1, near
+        print(f"48 layers, {'graph' if graph else 'eager'}: {B} x {steps} tokens, {int((got == ref).all(1).sum())} rows bit-equal, "
+              f"{near} near-tie divergences; oracle loop {t_cpu:.1f} s")
+
+
+@pytest.fixture(scope="module")
+def rar32():
+    from wmar_amd.models.engine import RAREngine
+    cfg = synth.RAR_XL
+    assert cfg.num_hidden_layers == 32 and cfg.hidden_size == 1280
+    sd_dev = synth.synth_rar_state(cfg, seed=32, device="cuda", logit_scale=8.0, gen_device="cuda")
+    eng = RAREngine(cfg, sd_dev, max_batch=64)
+    sd = _host(sd_dev)
+    del sd_dev
+    torch.cuda.empty_cache()
+    return eng, sd
+
+
+def test_rar_xl_32_layers_guided_loop_and_logits(rar32, kat, key_factory):
+    eng, sd = rar32
+    cfg = synth.RAR_XL
+    wm = _wm(kat["keys"]["rar"])
+    key = key_factory(kat["keys"]["rar"])
+    B, steps = 64, 12
+    cond = torch.tensor([(i * 13 + 1) % 1000 for i in range(B)])
+    g = torch.Generator().manual_seed(3232)
+    q = torch.empty(cfg.image_seq_len, B, cfg.codebook_size).exponential_(1, generator=g)
+    rec = []
+    t0 = time.perf_counter()
+    ref = R.generate(sd, cfg, cond, guidance_scale=4.0, guidance_scale_pow=0.0, key=key, delta=2.0,
+                     q_source=lambda n, b, v: q[n], record=rec, draw_drop_mask=False, max_steps=steps).numpy()
+    t_cpu = time.perf_counter() - t0
+    got = eng.generate(cond.cuda(), q.cuda(), R.cfg_scales(cfg.image_seq_len, 4.0, 0.0), 1.0, wm.wm_ctx()).cpu().numpy()
+    assert got.shape == (B, cfg.image_seq_len)
+    near = _compare_tokens(got[:, :steps], ref, rec, 16 * ATOL_DEPTH)        # the guidance mix (scale 4) multiplies logit differences by up to 7
+    assert near <= 1, near
+    # logits of the same positions, teacher-forced on the oracle's tokens (conditional rows, then unconditional rows)
+    ids = cond + cfg.codebook_size + 1
+    both = torch.cat([ids, torch.full_like(ids, cfg.none_condition_id)]).cuda()
+    eng.forward_position(torch.full((2 * B,), -1, dtype=torch.int64).cuda(), both, 0)
+    tok = both
+    worst = 0.0
+    for n in range(steps):
+        lg = eng.forward_position(tok, both, n + 1).cpu().numpy()
+        want = np.concatenate([rec[n]["cond_logits"], rec[n]["uncond_logits"]])
+        d = float(np.abs(lg - want).max())
+        worst = max(worst, d)
+        assert d < ATOL_DEPTH, (n, d)
+        t = torch.from_numpy(ref[:, n])
+        tok = torch.cat([t, t]).cuda()
+    print(f"RAR-XL 32 layers: {B} x {steps} guided tokens, {int((got[:, :steps] == ref).all(1).sum())} rows bit-equal, max |dlogit| {worst:.2e} over {steps} positions x {2 * B} rows; "
+          f"oracle {t_cpu:.1f} s")

@@ -95,11 +95,12 @@ def test_delta_checkpoints_equal_reference_update_weights(hv, tmp_path):
     assert (m.images_to_codes(img0).cpu().numpy() == hv["delta_codes_before"]).mean() >= 0.99
     torch.save(synth.synth_delta(vs, "decoder.", seed=1), tmp_path / "dec_delta.pth")
     torch.save({"state_dict": synth.synth_delta(vs, "encoder.", seed=2)}, tmp_path / "enc_delta.pth")   # Lightning-style nesting
-    update_weights(m, "decoder", str(tmp_path / "dec_delta.pth"))
+    r = update_weights(m.get_image_tokenizer().decoder, str(tmp_path / "dec_delta.pth"))      # the reference's call (generate.py:330-332)
+    assert not r.missing_keys and not r.unexpected_keys
     img1 = m.codes_to_images(codes)
     np.testing.assert_allclose(img1.cpu().numpy(), hv["delta_img_after"], rtol=0, atol=2e-4)
     assert float(np.abs(hv["delta_img_after"] - hv["delta_img_before"]).max()) > 1e-2       # the patch is not a no-op
-    update_weights(m, "encoder", str(tmp_path / "enc_delta.pth"))
+    update_weights(m, "encoder", str(tmp_path / "enc_delta.pth"))                              # rounds 1-4 form, still accepted
     c1 = m.images_to_codes(torch.from_numpy(hv["delta_img_after"]).cuda())
     assert (c1.cpu().numpy() == hv["delta_codes_after"]).mean() >= 0.99
     assert (hv["delta_codes_after"] != hv["delta_codes_before"]).mean() > 0.05               # the encoder patch moves codes

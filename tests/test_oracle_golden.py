@@ -113,6 +113,19 @@ def test_gpt_step_logits(golden):
         assert np.array_equal(lg.numpy().argmax(-1), golden["gpt_logits_argmax"][t])
 
 
+def test_gpt_prefix_pass_equals_the_reference_logits(golden):
+    """the one-pass masked prefix (GPT.forward_with_past with past=None, what tests/test_gpu_depth.py checks the 48-layer engine
+    against) gives the reference's incremental logits at every position."""
+    sd = synth.synth_gpt_state(SMALL_GPT, seed=3, logit_scale=40.0)
+    seq = torch.from_numpy(golden["gpt_seq"])
+    full = M.gpt_prefix(sd, SMALL_GPT.n_head, seq).numpy()
+    for t in range(seq.shape[1]):
+        np.testing.assert_allclose(full[:, t, ::16], golden["gpt_logits"][t], rtol=0, atol=2e-4)
+        assert np.array_equal(full[:, t].argmax(-1), golden["gpt_logits_argmax"][t])
+    sel = M.gpt_prefix(sd, SMALL_GPT.n_head, seq, [0, seq.shape[1] - 1]).numpy()
+    assert np.array_equal(sel, full[:, [0, seq.shape[1] - 1]])
+
+
 def test_sampling_stage_on_reference_logits(golden, kat, key_factory):
     """Stage-level: reference model logits + the noise multinomial drew -> the reference's tokens."""
     key = key_factory(kat["keys"]["taming"])

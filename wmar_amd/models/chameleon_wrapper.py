@@ -22,16 +22,9 @@ from ..utils.synth import CHAMELEON_7B, CHAMELEON_VQ, ChameleonConfig, VQConfig,
 from .armm_wrapper import AutoregressiveMultimodalModelWrapper
 from .chameleon import VocabInfo, VocabTranslation
 from .engine import ChameleonEngine, VQGANEngine
+from .tokenizer_handles import ImageTokenizerHandle
 
 _ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
-
-
-class _Quantize:
-    def __init__(self, weight):
-        self.n_e, self.e_dim = weight.shape
-        self.embedding = SimpleNamespace(weight=weight)
-        self.alive_ids = None
-        self.dead_ids = None
 
 
 def allow_bitmap(ids: Sequence[int], vocab_size: int, device) -> torch.Tensor:
@@ -85,7 +78,8 @@ class ChameleonARMMWrapper(AutoregressiveMultimodalModelWrapper):
         self._vq_cfg = vq_cfg
         self._vq_state = {k: v.detach().to(dev, torch.float32) for k, v in vq_state.items() if not k.startswith("loss.")}
         self._vq_engine = None
-        self._image_tokenizer = SimpleNamespace(quantize=_Quantize(self._vq_state["quantize.embedding.weight"]))
+        # token_manager.image_tokenizer._vq_model's place (chameleon_wrapper.py:44-45): handles on _vq_state
+        self._image_tokenizer = ImageTokenizerHandle(self._vq_state, self._drop_vq_engine)
         ids = os.path.join(_ASSETS, "chameleon_all_ids.txt")
         if vq_cfg.n_embed == 8192 and cfg.vocab_size == 65536 and os.path.exists(ids):
             self.init_alivecodes(ids)
@@ -117,6 +111,9 @@ class ChameleonARMMWrapper(AutoregressiveMultimodalModelWrapper):
 
     def __repr__(self):
         return "ChameleonARMMWrapper"
+
+    def _drop_vq_engine(self):
+        self._vq_engine = None  # repacked from _vq_state on next use
 
     @property
     def vq_engine(self) -> VQGANEngine:

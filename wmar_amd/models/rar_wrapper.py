@@ -15,6 +15,7 @@ from ..utils.synth import MASKGIT_VQ, RAR_XL, MaskgitVQConfig, RARConfig, synth_
 from .armm_wrapper import AutoregressiveMultimodalModelWrapper
 from ..watermarking.gumbel_watermark import GumbelWatermark
 from .engine import MaskgitVQEngine, RAREngine
+from .tokenizer_handles import ImageTokenizerHandle
 
 _ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
 _RAR_SIZES = {"rar_b": (768, 24, 3072), "rar_l": (1024, 24, 4096), "rar_xl": (1280, 32, 5120), "rar_xxl": (1408, 40, 6144)}
@@ -28,14 +29,6 @@ def cfg_scales(steps: int, guidance_scale: float, guidance_scale_pow: float) -> 
         scale_step = (1 - torch.cos(((step / steps) ** scale_pow) * torch.pi)) * 1 / 2
         out.append((guidance_scale - 1) * scale_step + 1)
     return torch.cat(out)
-
-
-class _Quantize:
-    def __init__(self, weight):
-        self.num_embeddings, self.embedding_dim = weight.shape
-        self.embedding = SimpleNamespace(weight=weight)
-        self.alive_ids = None
-        self.dead_ids = None
 
 
 class RarARMMWrapper(AutoregressiveMultimodalModelWrapper):
@@ -57,7 +50,8 @@ class RarARMMWrapper(AutoregressiveMultimodalModelWrapper):
         self._vq_cfg = vq_cfg
         self._vq_state = {k: v.detach().to(dev, torch.float32) for k, v in vq_state.items()}
         self._vq_engine = None
-        self.tokenizer = SimpleNamespace(quantize=_Quantize(self._vq_state["quantize.embedding.weight"]))
+        # PretrainedTokenizer's place (titok.py:24-89): .encoder / .decoder / .quantize as handles on _vq_state
+        self.tokenizer = ImageTokenizerHandle(self._vq_state, self._drop_vq_engine)
         ids = os.path.join(_ASSETS, "rar_all_ids.txt")
         if vq_cfg.num_embeddings == 1024 and os.path.exists(ids):
             self.init_alivecodes(ids)
@@ -79,6 +73,9 @@ class RarARMMWrapper(AutoregressiveMultimodalModelWrapper):
 
     def __repr__(self):
         return "RarARMMWrapper"
+
+    def _drop_vq_engine(self):
+        self._vq_engine = None  # repacked from _vq_state on next use
 
     @property
     def vq_engine(self) -> MaskgitVQEngine:

@@ -9,44 +9,18 @@ draws the Exp(1) noise ``torch.multinomial`` would draw.
 from __future__ import annotations
 
 import os
-import pickle
 from types import SimpleNamespace
 from typing import Dict, Optional
 
 import torch
 
+from ..utils.utils import tolerant_torch_load as _tolerant_torch_load
 from ..utils.synth import GPTConfig, VQConfig, synth_gpt_state, synth_gpt_state_fast, synth_vq_state, synth_vq_state_fast
 from .armm_wrapper import AutoregressiveMultimodalModelWrapper
 from .engine import GPTEngine, VQGANEngine
+from .tokenizer_handles import ImageTokenizerHandle
 
 _ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
-
-
-def _tolerant_torch_load(path):
-    """Lightning checkpoints pickle objects of packages that are not installed here
-    (pytorch_lightning, omegaconf); only ``state_dict`` matters, so unknown classes
-    are replaced by inert stand-ins while unpickling."""
-    try:
-        return torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:
-        pass
-
-    class _Stub:
-        def __init__(self, *a, **k):
-            pass
-
-        def __setstate__(self, s):
-            pass
-
-    class _Unpickler(pickle.Unpickler):
-        def find_class(self, module, name):
-            try:
-                return super().find_class(module, name)
-            except Exception:
-                return _Stub
-
-    pm = SimpleNamespace(Unpickler=_Unpickler, load=lambda f, **k: _Unpickler(f, **k).load(), __name__="tolerant_pickle")
-    return torch.load(path, map_location="cpu", weights_only=False, pickle_module=pm)
 
 
 def configs_from_yaml(config_path):
@@ -68,16 +42,6 @@ def configs_from_yaml(config_path):
     return g, v
 
 
-class _Quantize:
-    """What the watermarker and init_alivecodes need of VectorQuantizer2 (quantize.py:213-331)."""
-
-    def __init__(self, weight: torch.Tensor):
-        self.n_e, self.e_dim = weight.shape
-        self.embedding = SimpleNamespace(weight=weight)
-        self.alive_ids = None
-        self.dead_ids = None
-
-
 class _Net2Net:
     """Stands where ``Net2NetTransformer`` stands in the reference wrapper (``self.model``)."""
 
@@ -89,8 +53,12 @@ class _Net2Net:
         self.vq_state = {k: v.detach().to(self.device, torch.float32) for k, v in vq_state.items()
                          if not k.startswith("loss.")}
         self.transformer = GPTEngine(gpt_cfg, gpt_state, max_batch=max_batch, device=self.device)
-        self.first_stage_model = SimpleNamespace(quantize=_Quantize(self.vq_state["quantize.embedding.weight"]))
         self._vq_engine: Optional[VQGANEngine] = None
+        # VQModel's place: .encoder / .decoder / .quantize (+ quant convs) as state_dict()/load_state_dict() handles on vq_state
+        self.first_stage_model = ImageTokenizerHandle(self.vq_state, self._drop_vq_engine)
+
+    def _drop_vq_engine(self):
+        self._vq_engine = None  # repacked from vq_state on next use
 
     @property
     def vq_engine(self) -> VQGANEngine:
@@ -101,16 +69,8 @@ class _Net2Net:
     def apply_delta(self, prefix: str, ckpt_path: str):
         """update_weights(model.<prefix>, ckpt) with delta=True (wmar/utils/utils.py:47-66):
         ``*_delta.pth`` tensors are ADDED to the base weights key-wise."""
-        sd = _tolerant_torch_load(ckpt_path)
-        if "state_dict" in sd:
-            sd = sd["state_dict"]
-        for k, v in sd.items():
-            full = prefix + k
-            if full in self.vq_state:
-                self.vq_state[full] = self.vq_state[full] + v.to(self.device, torch.float32)
-            else:
-                self.vq_state[full] = v.to(self.device, torch.float32)
-        self._vq_engine = None  # repacked on next use
+        from ..utils.utils import update_weights
+        update_weights(getattr(self.first_stage_model, prefix.rstrip(".")), ckpt_path, delta=True)
 
 
 class TamingARMMWrapper(AutoregressiveMultimodalModelWrapper):
