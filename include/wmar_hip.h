@@ -30,6 +30,10 @@ extern "C" {
 #define WMAR_EINVAL (-1)   /* bad argument / unsupported shape            */
 #define WMAR_EHIP (-2)     /* HIP runtime error                           */
 #define WMAR_ESHORT (-3)   /* detect: len(codes) - context_size < 1       */
+/* LINEAR / FIXED seeding take any context size up to this (gentime_watermark.py:236-241 has no limit; the key table has
+ * context_size * (vocab - 1) + 1 rows of vocab / 8 bytes, so memory is the practical bound); SPATIAL: 1 or 3 as in the
+ * reference (:243); the Chameleon generation loop keeps 3 prompt tokens in front of the image tokens: context_size <= 3 there. */
+#define WMAR_MAX_CONTEXT 16
 #define WMAR_ENOMEM (-4)
 #define WMAR_EMISSING (-5) /* a required checkpoint tensor is missing      */
 
@@ -141,7 +145,8 @@ int wmar_gpt_decode_step(wmar_gpt* g, const int64_t* tok_dev, int64_t B, int32_t
  * device memory).  cond_dev int64 [B] (the class token), q_dev float [steps, B, V] (noise for
  * every step, see wmar_sample_fused), tokens_out_dev int64 [B, steps].
  * logits_trace_dev (nullable): float [steps, B, V], raw model logits per step.
- * Asynchronous: everything is ordered on `stream`; one generate per engine at a time. */
+ * Everything is ordered on `stream`; one generate per engine at a time.  Asynchronous on the two-launch path; while the fused
+ * projection launch is in use the call waits for its replays and verifies the in-launch barrier (see wmar_gpt_check). */
 typedef struct wmar_sample_params {
     float temperature;
     int32_t top_k;  /* <= 0: off */
@@ -167,11 +172,16 @@ int wmar_gpt_generate(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_para
 #define WMAR_T_HEAD 7    /* ln_f -> vocabulary head GEMM                       */
 #define WMAR_T_SAMPLE 8  /* fused watermark + sampling                         */
 #define WMAR_T_NCLASS 9
-/* Waits for `stream` and reports whether the XCD-local barrier of the fused projection launch (k_bx_xr: output projection +
- * residual fold + LayerNorm statistics in one launch, batches of 33..64 rows) gave up or found a block on a foreign XCD since the
- * last check.  WMAR_EHIP = the results of the calls since the last check are invalid; the engine continues on the two-launch path.
- * wmar_gpt_create probes the block -> XCD grouping and only then enables the fused launch (WMAR_NO_XR=1 at creation disables it).
- * The Python engine calls this after every generation.  No reference counterpart (no in-kernel synchronisation there). */
+/* In-launch synchronisation (no reference counterpart).  At batches of 33..64 rows the output projection, its split-K reduction,
+ * the residual fold and the LayerNorm statistics run as ONE launch (k_bx_xr) behind an XCD-local barrier.  wmar_gpt_create enables it
+ * only when blocks with equal blockIdx % 8 share an XCD and the device holds the whole grid at once (WMAR_NO_XR=1 at creation keeps
+ * the two-launch path: k_bx + k_resid_stats).  Every wait is bounded; a wait that gives up, or a block on a foreign XCD, raises a
+ * device flag, later waits leave at once, and wmar_gpt_generate / wmar_gpt_decode_step -- which wait for the stream and read the
+ * flags while the fused launch is in use -- switch the engine to the two-launch path and RE-RUN the call (same inputs: same
+ * results; wmar_gpt_plan_info reports `barrier_fallbacks`).  On the two-launch path both calls are asynchronous again.
+ * wmar_gpt_check does the same flag test for callers that enqueue single roles (wmar_gpt_profile_role): WMAR_EHIP = the launches
+ * since the last check are invalid, the engine continues on the two-launch path.  WMAR_INJECT_SYNC_FAIL=1 at creation (tests)
+ * raises the flag in front of the first fused call. */
 int wmar_gpt_check(wmar_gpt* g, void* stream);
 int wmar_gpt_set_timing(wmar_gpt* g, int32_t enabled);
 /* Decode attention runs 1 / 2 / 4 waves per (sequence, head) while the cache holds <= one_wave_upto / <= two_waves_upto /
@@ -232,11 +242,14 @@ int wmar_rar_generate_gumbel(wmar_rar* g, const int64_t* class_ids_dev, int64_t 
                              int32_t use_guidance, float temperature, float top_p, int32_t top_k,
                              const float* log_rs_dev, int64_t* tokens_out_dev, int32_t use_graph, void* stream);
 
-/* Waits for `stream` and reports whether an in-launch wait of the engine gave up since the last check (the fused residual +
- * modulation launch of a RAR block lets its workgroups wait for each other's partial sums; wmar_rar_create verifies that the
- * device holds them all at once, a wait that still gives up after 2^20 polls raises a device flag).  WMAR_EHIP = the results of
- * the calls since the last check are invalid.  The Python engine calls it after every generation (no reference counterpart:
- * the reference has no in-kernel synchronisation). */
+/* In-launch synchronisation of the RAR engine: the fused residual + adaLN modulation launch of a block (k_resid_mod) lets its
+ * workgroups wait for each other's partial sums.  wmar_rar_create enables it when the device holds the whole grid at once
+ * (occupancy x compute units; WMAR_NO_XR=1 disables it), otherwise the same work runs as a two-launch pair (bit-identical results).
+ * A wait that gives up raises a device flag; wmar_rar_generate* / wmar_rar_forward_position wait for the stream while the fused
+ * launch is in use, and on a raised flag switch to the two-launch pair and RE-RUN the call.  wmar_rar_check: the same flag test
+ * for other callers (WMAR_EHIP = the launches since the last check are invalid).  wmar_rar_launch_status: whether the fused
+ * launch is still in use, and how many calls were re-run. */
+int wmar_rar_launch_status(const wmar_rar* g, int32_t* fused, int32_t* fallbacks);
 int wmar_rar_check(wmar_rar* g, void* stream);
 
 /* ----------------------------------------------------------------- Gumbel key (row G1)

@@ -672,6 +672,50 @@ def spatial_vectors(args):
     print("wrote spatial_vectors.npz", os.path.getsize(os.path.join(HERE, "spatial_vectors.npz")), "bytes")
 
 
+def linear_h_vectors(args):
+    """LINEAR seeding with context sizes beyond 3 (gentime_watermark.py:236-241 takes any `context_size`): the reference's sampling
+    loop (mingpt.py:326-368) with h = 4 and h = 5 on the 2-layer / 128-wide GPT of the other loop fixtures (V = 16384, 24 steps),
+    its detector (p-values, masks) on those tokens, and the logit processor on a past that is too short for some rows."""
+    import torch
+    from deps.taming.modules.transformer.mingpt import GPT, sample_with_past
+    from wmar.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
+    from wmar_amd.utils import synth
+    import contextlib, io
+
+    ids = []
+    for line in open(os.path.join(args.ref, "assets", "vqgan_alive_ids.txt")):
+        ids.extend(int(t) for t in line.split(","))
+    dead = list(set(range(16384)) - set(ids))
+    vq = {"alive_ids": torch.tensor(ids), "dead_ids": torch.tensor(dead), "embedding": torch.zeros(16384, 4)}
+    cfg = synth.GPTConfig(vocab_size=16384, block_size=24, n_layer=2, n_head=4, n_embd=128)
+    sd = synth.synth_gpt_state(cfg, seed=3, logit_scale=40.0, with_mask=True)
+    gpt = GPT(vocab_size=cfg.vocab_size, block_size=cfg.block_size, n_layer=cfg.n_layer, n_head=cfg.n_head, n_embd=cfg.n_embd)
+    gpt.load_state_dict(sd, strict=True)
+    gpt.eval()
+    cond = torch.tensor([[7], [980], [1], [340]], dtype=torch.long)
+    out = {"cond": cond.numpy()}
+    rs = np.random.RandomState(44)
+    logits = torch.from_numpy(rs.randn(3, 16384).astype(np.float32) * 3)
+    for h in (4, 5):
+        wm = GentimeWatermark(vq, 16384, SeedStrategy.LINEAR, SplitStrategy.RANDOM_STRATIFIED, h, 2.0, 0.25)
+        torch.manual_seed(11)
+        with contextlib.redirect_stdout(io.StringIO()):
+            toks = sample_with_past(cond, gpt, steps=24, temperature=1.0, sample_logits=True, top_k=250, top_p=0.92,
+                                    logit_processor=wm.spawn_logit_processor())
+            pv, masks = wm.detect(toks, return_masks=True)
+        out[f"tokens_h{h}"] = toks.numpy()
+        out[f"pvals_h{h}"] = pv.numpy()
+        out[f"masks_h{h}"] = np.array(masks, dtype=np.int8)
+        # logit processor: a past of exactly h tokens (bias applied) and one of h - 1 (every row skipped, gentime_watermark.py:237-240)
+        past = torch.from_numpy(rs.randint(0, 16384, size=(3, h)).astype(np.int64))
+        out[f"proc_past_h{h}"] = past.numpy()
+        out[f"proc_out_h{h}"] = wm.spawn_logit_processor()(past_ids=past, logits=logits.clone()).numpy()
+        out[f"proc_short_out_h{h}"] = wm.spawn_logit_processor()(past_ids=past[:, :h - 1], logits=logits.clone()).numpy()
+    out["proc_logits"] = logits.numpy()
+    np.savez_compressed(os.path.join(HERE, "linear_h_vectors.npz"), **out)
+    print("wrote linear_h_vectors.npz", os.path.getsize(os.path.join(HERE, "linear_h_vectors.npz")), "bytes")
+
+
 def fullsize_vq_vectors(args):
     """The three image tokenizers at the shapes the benchmarks run, from the reference's own
     modules on seeded weights (synth.*_state(seed) regenerates them bit for bit wherever the fixture is used):
@@ -805,18 +849,18 @@ def fullsize_vq_vectors(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--only", default="", help="'gumbel' / 'chameleon' / 'prod' / 'sampler' / 'harness' / 'spatial' / 'fullvq': regenerate only that fixture file")
+    ap.add_argument("--only", default="", help="'gumbel' / 'chameleon' / 'prod' / 'sampler' / 'harness' / 'spatial' / 'linearh' / 'fullvq': regenerate only that fixture file")
     args = ap.parse_args()
     if args.only == "gumbel":
         gumbel_vectors(args)
         return
-    if args.only in ("chameleon", "prod", "sampler", "harness", "spatial", "fullvq"):
+    if args.only in ("chameleon", "prod", "sampler", "harness", "spatial", "linearh", "fullvq"):
         tmp = tempfile.mkdtemp(prefix="wmar_stubs_")
         _stubs(tmp)
         sys.path[:0] = [tmp, args.ref, REPO]
         os.chdir(args.ref)
         {"chameleon": chameleon_vectors, "prod": prod_vectors, "sampler": sampler_bulk_vectors, "harness": harness_vectors, "spatial": spatial_vectors,
-         "fullvq": fullsize_vq_vectors}[args.only](args)
+         "linearh": linear_h_vectors, "fullvq": fullsize_vq_vectors}[args.only](args)
         return
     tmp = tempfile.mkdtemp(prefix="wmar_stubs_")
     _stubs(tmp)

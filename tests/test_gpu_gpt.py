@@ -105,3 +105,33 @@ def test_generate_spatial_seeding_reproduces_reference_tokens(kat, small_engine,
     pv, masks = wm.detect(toks, return_masks=True)
     assert np.allclose(pv.cpu().numpy(), sv[f"pvals_h{h}"], rtol=1e-9, atol=0, equal_nan=True)
     assert np.array_equal(np.array(masks, dtype=np.int8), sv[f"masks_h{h}"])
+
+
+@pytest.mark.parametrize("h", [4, 5])
+def test_generate_linear_context_beyond_3_reproduces_reference_tokens(kat, h):
+    """LINEAR seeding with context sizes 4 and 5 -- the reference takes any `context_size` (gentime_watermark.py:236-241); the key
+    table has h * (V - 1) + 1 rows.  The reference's loop, detector (p-values, masks) and logit processor, incl. the rows whose
+    context is too short (tests/golden/linear_h_vectors.npz, make_golden.py linear_h_vectors)."""
+    import os
+    from tests.conftest import REPO
+    from wmar_amd.models.engine import GPTEngine
+    lv = np.load(os.path.join(REPO, "tests", "golden", "linear_h_vectors.npz"))
+    cfg = synth.GPTConfig(vocab_size=16384, block_size=24, n_layer=2, n_head=4, n_embd=128)
+    eng = GPTEngine(cfg, synth.synth_gpt_state(cfg, seed=3, logit_scale=40.0), max_batch=4)
+    wm = _wm(kat["keys"]["taming"], h=h)
+    assert wm.key_table().shape[0] == h * 16383 + 1
+    torch.manual_seed(11)
+    q = torch.stack([torch.empty(4, 16384).exponential_(1) for _ in range(24)]).cuda()
+    for graph in (True, False):
+        toks = eng.generate(torch.from_numpy(lv["cond"]).view(-1).cuda(), 24, q, 1.0, 250, 0.92, wm.wm_ctx(), use_graph=graph)
+        assert np.array_equal(toks.cpu().numpy(), lv[f"tokens_h{h}"])
+    pv, masks = wm.detect(toks, return_masks=True)
+    assert np.allclose(pv.cpu().numpy(), lv[f"pvals_h{h}"], rtol=1e-9, atol=0, equal_nan=True)
+    assert np.array_equal(np.array(masks, dtype=np.int8), lv[f"masks_h{h}"])
+    proc = wm.spawn_logit_processor()
+    past = torch.from_numpy(lv[f"proc_past_h{h}"]).cuda()
+    lg = torch.from_numpy(lv["proc_logits"]).cuda()
+    assert np.array_equal(proc(past_ids=past, logits=lg.clone()).cpu().numpy(), lv[f"proc_out_h{h}"])
+    assert np.array_equal(proc(past_ids=past[:, :h - 1], logits=lg.clone()).cpu().numpy(), lv[f"proc_short_out_h{h}"])
+    from wmar_amd.watermarking.gentime_watermark import clear_key_cache
+    clear_key_cache()       # 128 / 160 MiB tables

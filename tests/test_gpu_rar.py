@@ -181,3 +181,47 @@ def test_rar_wrapper_end_to_end(kat):
     assert c2.shape == codes.shape
     pv = wm.detect(codes)
     assert float(pv.min()) < 1e-3     # delta=4 watermark is clearly detectable on the generated codes
+
+
+_CHILD_RM = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from oracle import rar_oracle as R
+from wmar_amd.utils import synth
+from wmar_amd.models.engine import RAREngine
+cfg = synth.RARConfig(hidden_size=1280, num_hidden_layers=2, num_attention_heads=16, intermediate_size=5120, image_seq_len=256,
+                      codebook_size=1024, condition_num_classes=1000)
+eng = RAREngine(cfg, synth.synth_rar_state(cfg, seed=12, logit_scale=8.0), max_batch=64)
+print("STATUS0", eng.launch_status())
+B = 64
+q = torch.empty(256, B, 1024).exponential_(1, generator=torch.Generator().manual_seed(3)).cuda()
+cond = (torch.arange(B) * 13 %% 1000).cuda()
+tok = eng.generate(cond, q, R.cfg_scales(256, 4.0, 0.0), 1.0, None)
+ids = cond.cpu() + cfg.codebook_size + 1
+both = torch.cat([ids, torch.full_like(ids, cfg.none_condition_id)]).cuda()
+lg = eng.forward_position(torch.full((2 * B,), -1, dtype=torch.int64).cuda(), both, 0)
+print("STATUS1", eng.launch_status())
+np.savez(sys.argv[1], tokens=tok.cpu().numpy(), logits=lg.cpu().numpy())
+"""
+
+
+def test_resid_mod_fallback_pair_is_bit_identical_and_recovers_a_failed_wait(tmp_path):
+    """k_resid_mod as ONE launch (in-launch wait), as the two-launch pair from the start (WMAR_NO_XR=1), and with the wait flag
+    raised in front of the first call (WMAR_INJECT_SYNC_FAIL=1: the call notices, switches to the pair and re-runs): the same
+    tokens and logits bit for bit at RAR-XL width (2 layers x 1280, 128 rows under guidance, 256 positions)."""
+    import subprocess
+    import sys
+    runs = {}
+    for name, env in (("fused", {}), ("pair", {"WMAR_NO_XR": "1"}), ("hurt", {"WMAR_INJECT_SYNC_FAIL": "1"})):
+        out = tmp_path / f"{name}.npz"
+        res = subprocess.run([sys.executable, "-c", _CHILD_RM % REPO, str(out)], env=dict(os.environ, **env), capture_output=True,
+                             text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        st = {l.split()[0]: eval(l.split(None, 1)[1]) for l in res.stdout.splitlines() if l.startswith("STATUS")}
+        runs[name] = (np.load(out), st)
+    assert runs["fused"][1]["STATUS0"] == {"fused": 1, "fallbacks": 0} == runs["fused"][1]["STATUS1"]
+    assert runs["pair"][1]["STATUS1"] == {"fused": 0, "fallbacks": 0}
+    assert runs["hurt"][1]["STATUS0"]["fused"] == 1 and runs["hurt"][1]["STATUS1"] == {"fused": 0, "fallbacks": 1}
+    for name in ("pair", "hurt"):
+        assert np.array_equal(runs[name][0]["tokens"], runs["fused"][0]["tokens"]), name
+        assert np.array_equal(runs[name][0]["logits"], runs["fused"][0]["logits"]), name

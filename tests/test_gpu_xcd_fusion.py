@@ -47,8 +47,8 @@ def test_fused_projection_matches_the_two_launch_path(tmp_path):
     fused, plan_f = _run(tmp_path, "fused", {})
     plain, plan_p = _run(tmp_path, "plain", {"WMAR_NO_XR": "1"})
     assert "k_bx<1" in plan_p
-    if "k_bx_xr" not in plan_f:
-        pytest.skip("the block -> XCD grouping probe did not enable the fused launch on this device: " + plan_f)
+    # gfx950 in SPX mode: the probe must enable the fused launch -- a regression that silently keeps the two-launch path fails here
+    assert "k_bx_xr" in plan_f, "the block -> XCD grouping probe did not enable the fused launch on this device: " + plan_f
     d = np.abs(fused["logits"] - plain["logits"]).max()
     assert d <= 2e-5, d
     assert np.array_equal(fused["tokens"], plain["tokens"])
@@ -69,3 +69,48 @@ def test_status_entry_point_and_phase_reset():
     assert eng.plan_info(8)["attn"] != auto
     eng.set_attention_phases(-1, -1)
     assert eng.plan_info(8)["attn"] == auto
+
+
+_CHILD_FALLBACK = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from wmar_amd.utils import synth
+from wmar_amd.models.engine import GPTEngine
+mode = sys.argv[2]
+cfg = synth.GPTConfig(vocab_size=16384, block_size=256, n_layer=3, n_head=24, n_embd=1536)
+eng = GPTEngine(cfg, synth.synth_gpt_state(cfg, seed=3, logit_scale=10.0), max_batch=64)
+print("PLAN0", eng.plan_info(64)["proj"])
+seq = torch.randint(0, cfg.vocab_size, (64, 6), generator=torch.Generator().manual_seed(5)).cuda()
+q = torch.empty(48, 64, cfg.vocab_size).exponential_(1, generator=torch.Generator().manual_seed(7)).cuda()
+if mode == "step_first":
+    out = [eng.decode_step(seq[:, t], t).cpu().numpy() for t in range(6)]
+    tok = eng.generate(torch.arange(64).cuda(), 48, q, 1.0, 250, 0.92, None, use_graph=True)
+else:
+    tok = eng.generate(torch.arange(64).cuda(), 48, q, 1.0, 250, 0.92, None, use_graph=True)
+    out = [eng.decode_step(seq[:, t], t).cpu().numpy() for t in range(6)]
+info = eng.plan_info(64)
+print("PLAN1", info["proj"])
+print("FALLBACKS", info["barrier_fallbacks"])
+np.savez(sys.argv[1], logits=np.stack(out), tokens=tok.cpu().numpy())
+"""
+
+
+def _run_fb(tmp_path, name, mode, env_extra):
+    out = tmp_path / f"{name}.npz"
+    res = subprocess.run([sys.executable, "-c", _CHILD_FALLBACK % REPO, str(out), mode], env=dict(os.environ, **env_extra),
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    tags = {l.split()[0]: l.split(None, 1)[1] for l in res.stdout.splitlines() if l.split() and l.split()[0] in ("PLAN0", "PLAN1", "FALLBACKS")}
+    return np.load(out), tags
+
+
+@pytest.mark.parametrize("mode", ["generate_first", "step_first"])
+def test_failed_barrier_falls_back_to_the_two_launch_path_and_reruns(tmp_path, mode):
+    """WMAR_INJECT_SYNC_FAIL=1 raises the barrier-timeout flag in front of the first fused call: its waits leave at once (garbage
+    results), the call notices, switches the engine to k_bx + k_resid_stats and re-runs -- the caller gets the two-launch path's
+    tokens / logits, no exception, and the engine stays on that path (plan_info: barrier_fallbacks = 1)."""
+    plain, _ = _run_fb(tmp_path, "plain", mode, {"WMAR_NO_XR": "1"})
+    hurt, tags = _run_fb(tmp_path, "hurt", mode, {"WMAR_INJECT_SYNC_FAIL": "1"})
+    assert "k_bx_xr" in tags["PLAN0"] and "k_bx<1" in tags["PLAN1"] and tags["FALLBACKS"] == "1", tags
+    assert np.array_equal(hurt["tokens"], plain["tokens"])
+    assert np.array_equal(hurt["logits"], plain["logits"])          # after the fallback the very same launches run

@@ -232,3 +232,26 @@ def test_oracle_spatial_loop_reproduces_reference_tokens(kat, key_factory):
         q = [torch.empty(4, 16384).exponential_(1) for _ in range(16)]
         toks = M.sample_with_past(sd, cfg.n_head, torch.from_numpy(sv["cond"]), 16, 1.0, 250, 0.92, key, 2.0, q_source=lambda n, b, v: q[n])
         assert np.array_equal(toks.numpy(), sv[f"tokens_h{h}"]), h
+
+
+@pytest.mark.parametrize("h", [4, 5])
+def test_oracle_linear_context_beyond_3_equals_the_reference(kat, key_factory, h):
+    """LINEAR seeding with h = 4 / 5 (the reference takes any context size, gentime_watermark.py:236-241): the oracle's loop,
+    detector and logit processor against tests/golden/linear_h_vectors.npz (make_golden.py linear_h_vectors)."""
+    import os
+    from tests.conftest import REPO
+    lv = np.load(os.path.join(REPO, "tests", "golden", "linear_h_vectors.npz"))
+    cfg = synth.GPTConfig(vocab_size=16384, block_size=24, n_layer=2, n_head=4, n_embd=128)
+    sd = synth.synth_gpt_state(cfg, seed=3, logit_scale=40.0)
+    key = key_factory(kat["keys"]["taming"], context_size=h)
+    torch.manual_seed(11)
+    q = [torch.empty(4, 16384).exponential_(1) for _ in range(24)]
+    toks = M.sample_with_past(sd, cfg.n_head, torch.from_numpy(lv["cond"]), 24, 1.0, 250, 0.92, key, 2.0, q_source=lambda n, b, v: q[n])
+    assert np.array_equal(toks.numpy(), lv[f"tokens_h{h}"])
+    pv, ns, ng, masks = W.detect(key, lv[f"tokens_h{h}"], return_masks=True)
+    assert np.allclose(pv, lv[f"pvals_h{h}"], rtol=1e-9, atol=0, equal_nan=True)
+    assert np.array_equal(np.array(masks, dtype=np.int8), lv[f"masks_h{h}"])
+    past = lv[f"proc_past_h{h}"]
+    assert np.array_equal(W.process_logits(key, past, lv["proc_logits"], 2.0), lv[f"proc_out_h{h}"])
+    assert np.array_equal(W.process_logits(key, past[:, :h - 1], lv["proc_logits"], 2.0), lv[f"proc_short_out_h{h}"])
+    assert np.array_equal(lv[f"proc_short_out_h{h}"], lv["proc_logits"])          # too-short context: every row skipped

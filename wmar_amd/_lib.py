@@ -20,7 +20,7 @@ SYMBOLS = [
     "wmar_gpt_set_timing", "wmar_gpt_set_attention_phases", "wmar_gpt_get_timing", "wmar_gpt_profile_role", "wmar_gpt_plan_info", "wmar_gpt_check", "wmar_rar_create", "wmar_rar_destroy",
     "wmar_rar_device_bytes", "wmar_rar_forward_position", "wmar_rar_generate", "wmar_vq_create", "wmar_vq_destroy", "wmar_vq_device_bytes",
     "wmar_vq_decode", "wmar_vq_encode", "wmar_mvq_create", "wmar_mvq_destroy", "wmar_mvq_device_bytes", "wmar_mvq_decode",
-    "wmar_mvq_encode", "wmar_gumbel_key_build", "wmar_gumbel_sample", "wmar_gumbel_score", "wmar_rar_generate_gumbel", "wmar_rar_check",
+    "wmar_mvq_encode", "wmar_gumbel_key_build", "wmar_gumbel_sample", "wmar_gumbel_score", "wmar_rar_generate_gumbel", "wmar_rar_check", "wmar_rar_launch_status",
     "wmar_cham_create", "wmar_cham_destroy", "wmar_cham_device_bytes", "wmar_cham_forward_tokens", "wmar_cham_generate_image",
     "wmar_cham_sample",
 ]
@@ -139,6 +139,7 @@ def load():
     L.wmar_rar_generate.argtypes = [vp, C.POINTER(WmCtx), vp, i64, C.POINTER(f32), i32, f32, vp, vp, i32, vp]
     L.wmar_rar_generate_gumbel.argtypes = [vp, vp, i64, C.POINTER(f32), i32, f32, f32, i32, vp, vp, i32, vp]
     L.wmar_rar_check.argtypes = [vp, vp]
+    L.wmar_rar_launch_status.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.wmar_gumbel_key_build.argtypes = [C.c_uint64, i64, vp, vp, vp]
     L.wmar_gumbel_sample.argtypes = [vp, i64, i64, vp, i64, i32, f32, f32, i32, vp, vp]
     L.wmar_gumbel_score.argtypes = [vp, i64, i64, i64, vp, i64, vp, vp, vp]

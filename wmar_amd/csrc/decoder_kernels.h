@@ -1450,6 +1450,20 @@ __device__ __forceinline__ unsigned l2_read_u32(unsigned* p) {
     asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p), "v"(z) : "memory");
     return v;
 }
+// returning add / swap performed by THIS XCD's L2 (sc0 = return the old value; no sc1: the request stops at the L2)
+__device__ __forceinline__ unsigned l2_add_u32(unsigned* p, unsigned v) {
+    unsigned o;
+    asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(o) : "v"(p), "v"(v) : "memory");
+    return o;
+}
+// fire-and-forget forms (no return value, nothing to wait for)
+__device__ __forceinline__ void l2_add_u32_noret(unsigned* p, unsigned v) {
+    asm volatile("global_atomic_add %0, %1, off" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void l2_swap_u32_noret(unsigned* p, unsigned v) {
+    asm volatile("global_atomic_swap %0, %1, off" :: "v"(p), "v"(v) : "memory");
+}
+constexpr int XR_MAX_POLLS = 1 << 15;      // ~20 ms of polling against a 1.8 us barrier
 __device__ __forceinline__ unsigned xcc_id() {
     unsigned x;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
@@ -1470,7 +1484,7 @@ __global__ __launch_bounds__(256) void k_bx_xr(BxrArgs q) {
     unsigned gen0 = 0, xid = 0;
     if (threadIdx.x == 0) {
         xid = xcc_id();
-        if (c == 0) __hip_atomic_store(q.sync + grp * 64 + 16, xid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (c == 0) l2_swap_u32_noret(q.sync + grp * 64 + 16, xid);
         gen0 = __hip_atomic_load(q.sync + grp * 64 + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // global_load sc1: served by the L2
     }
     // ---------------------------------------------------------------------------------------------------- phase 1 (k_bx<1, PER>)
@@ -1541,16 +1555,25 @@ __global__ __launch_bounds__(256) void k_bx_xr(BxrArgs q) {
         unsigned* cnt = q.sync + grp * 64;
         unsigned* gen = cnt + 32;
         const unsigned members = (unsigned)(q.tiles_per_group * S);
-        // workgroup-scope atomics on global memory: global_atomic without sc1, performed by THIS XCD's L2
-        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // The arrive / reset / release atomics are spelled out (no sc1: performed by THIS XCD's L2, they never leave the XCD), so the
+        // cache policy does not depend on how the compiler lowers a memory scope.
+        const unsigned old = l2_add_u32(cnt, 1u);
         if (old == members - 1u) {
-            __hip_atomic_exchange(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            l2_swap_u32_noret(cnt, 0u);
+            l2_add_u32_noret(gen, 1u);
         } else {
+            // Bounded wait: the barrier takes 1.8 us on a healthy device (polls of ~0.5 us).  A launch whose workgroups are not all
+            // resident (a CU mask, a partition mode, another process on the device) would otherwise spin for seconds in each of the
+            // 48 x 256 launches of a captured loop: the first wait that gives up raises fail[1], every later wait -- in this launch
+            // and in the launches behind it -- sees the flag and leaves at once, and the host (gpt_verify) re-runs the call on the
+            // two-launch path.
             int spins = 0;
-            while (l2_read_u32(gen) == gen0) {
+            bool dead = __hip_atomic_load(q.fail + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            while (!dead && l2_read_u32(gen) == gen0) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1 << 22)) { __hip_atomic_store(q.fail + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                ++spins;
+                if ((spins & 255) == 0) dead = __hip_atomic_load(q.fail + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                if (spins > XR_MAX_POLLS) { __hip_atomic_store(q.fail + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
         }
         if (l2_read_u32(q.sync + grp * 64 + 16) != xid) __hip_atomic_store(q.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -92,6 +92,8 @@ struct wmar_gpt {
     unsigned* xsync = nullptr;     // [8][64] barrier words, [8*64 ..] = fail flags (placement, timeout)
     bool xcd_ok = false;           // blocks with equal blockIdx % 8 share an XCD, eight distinct XCDs (k_xcc_probe)
     bool no_xr = false;            // WMAR_NO_XR=1 at creation: keep the two-launch path
+    int inject_fail = 0;           // WMAR_INJECT_SYNC_FAIL=1 at creation (tests): the next fused call finds the timeout flag raised
+    int fallbacks = 0;             // calls re-run on the two-launch path after a failed in-launch barrier (wmar_gpt_plan_info reports it)
     unsigned long long* dbg_sums = nullptr; int dbg_slot = 0;   // dev only: see k_dbg_sum
     bool no_bx = false;           // dev knob WMAR_NO_BX: keep the fp32-MFMA k_qkvx
     int force_s[3] = {0, 0, 0};   // tuning knobs: WMAR_S_QKV / WMAR_S_PROJ / WMAR_S_FC2
@@ -644,7 +646,14 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
             for (int x = 0; x < 8 && ok; ++x) { ok = !(seen & (1u << h[x])); seen |= 1u << h[x]; }
         }
         if (tmp) (void)hipFree(tmp);
+        // ... and every workgroup of its grid must be resident at once: one per CU at least (a CU mask or a partition mode shrinks
+        // what the runtime reports)
+        int nb = 0, dev = 0, cus = 0;
+        if (ok) ok = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bx_xr<BX_PER, 4>, 256, 0) == hipSuccess && hipGetDevice(&dev) == hipSuccess &&
+                     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+                     (long long)nb * cus >= (long long)(D / 32) * 4;
         g->xcd_ok = ok;
+        { const char* e = getenv("WMAR_INJECT_SYNC_FAIL"); g->inject_fail = (e && atoi(e) > 0) ? 1 : 0; }
     }
     if (rc != WMAR_OK) { delete g; return rc; }
     *out = g;
@@ -652,24 +661,39 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
 }
 
 // The fused projection launch (k_bx_xr) raises device flags when its XCD-local barrier gives up or a block sits on a foreign XCD.
-static int gpt_sync_status(wmar_gpt* g, hipStream_t st) {
-    if (!g->xsync) return WMAR_OK;
+// Returns 1 when a flag was up: the engine has then been switched to the two-launch path (k_bx + k_resid_stats), its graphs dropped
+// and the flags cleared -- the caller re-runs its work, which is deterministic in its inputs.  0: clean.  < 0: HIP error.
+static int gpt_sync_failed(wmar_gpt* g, hipStream_t st) {
+    if (!g->xsync || !g->xcd_ok) return 0;
     unsigned f[2] = {0, 0};
     WMAR_HIP_CHECK(hipMemcpyAsync(f, g->xsync + 8 * 64, 8, hipMemcpyDeviceToHost, st));
     WMAR_HIP_CHECK(hipStreamSynchronize(st));
-    if (f[0] || f[1]) {
-        g->drop_graph();
-        (void)hipMemsetAsync(g->xsync, 0, (8 * 64 + 64) * 4, st);
-        g->xcd_ok = false;                  // the two-launch path from here on
-        set_error("gpt: the XCD-local barrier of the fused projection launch %s: the results of the calls since the last check are invalid "
-                  "(the engine continues on the two-launch path)", f[0] ? "found a block on a foreign XCD" : "timed out");
-        return WMAR_EHIP;
-    }
-    return WMAR_OK;
+    if (!f[0] && !f[1]) return 0;
+    g->drop_graph();
+    WMAR_HIP_CHECK(hipMemsetAsync(g->xsync, 0, (8 * 64 + 64) * 4, st));
+    g->xcd_ok = false;                  // the two-launch path from here on
+    g->fallbacks += 1;
+    return 1;
+}
+// tests: raise the timeout flag in front of the next fused call, once
+static int gpt_inject(wmar_gpt* g, hipStream_t st) {
+    if (!g->inject_fail || !g->xcd_ok) return WMAR_OK;
+    g->inject_fail = 0;
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, (int*)(g->xsync + 8 * 64 + 1), 1);
+    return launch_status("k_set_int");
 }
 int wmar_gpt_check(wmar_gpt* g, void* stream) {
     WMAR_REQUIRE(g, "gpt_check: null argument");
-    return gpt_sync_status(g, (hipStream_t)stream);
+    // generate / decode_step verify and recover by themselves; this entry point remains for callers that enqueue single roles
+    // (wmar_gpt_profile_role) and want to know whether the fused launch still runs
+    const int f = gpt_sync_failed(g, (hipStream_t)stream);
+    if (f < 0) return f;
+    if (f > 0) {
+        set_error("gpt: the XCD-local barrier of the fused projection launch gave up or found a block on a foreign XCD: the launches since "
+                  "the last check are invalid (the engine continues on the two-launch path)");
+        return WMAR_EHIP;
+    }
+    return WMAR_OK;
 }
 
 void wmar_gpt_destroy(wmar_gpt* g) { delete g; }
@@ -680,10 +704,20 @@ int wmar_gpt_decode_step(wmar_gpt* g, const int64_t* tok_dev, int64_t B, int32_t
     WMAR_REQUIRE(B >= 1 && B <= g->Bmax, "decode_step: batch %lld outside 1..%d", (long long)B, g->Bmax);
     WMAR_REQUIRE(pos >= 0 && pos < g->Tmax, "decode_step: position %d outside the block size %d", pos, g->Tmax);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, g->pos_dev, (int)pos);
     StepIO io{(const long long*)tok_dev, 1, 0, logits_dev};
     g->att_nw = wmar_gpt::phase_waves(g->att_phase(pos + 1, B));
-    return enqueue_step(g, B, io, st);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (int rc = gpt_inject(g, st)) return rc;
+        hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, g->pos_dev, (int)pos);
+        if (int rc = enqueue_step(g, B, io, st)) return rc;
+        // on the fused path the call waits for the step and checks the in-launch barrier; a failed step is re-run on the two-launch
+        // path (the step is a pure function of the token, the position and the cache rows below it)
+        const int f = gpt_sync_failed(g, st);
+        if (f < 0) return f;
+        if (f == 0) return WMAR_OK;
+    }
+    set_error("decode_step: the in-launch barrier flag is up on the two-launch path");
+    return WMAR_EHIP;
 }
 
 int wmar_gpt_profile_role(wmar_gpt* g, int32_t role, int64_t B, int32_t kv_len, int32_t iters, void* stream,
@@ -755,8 +789,8 @@ int wmar_gpt_plan_info(wmar_gpt* g, int64_t B, char* buf, int64_t buf_len) {
               w2 = wmar_gpt::phase_waves(g->att_phase(g->Tmax, B));
     if (w0 == w1 && w1 == w2) snprintf(attn, sizeof attn, "k_attn_decode<%d,%d>", g->hd, w1);
     else snprintf(attn, sizeof attn, "k_attn_decode<%d,%d> (%d / %d / %d waves at 1 / %d / %d cached rows)", g->hd, w1, w0, w1, w2, g->Tmax / 2, g->Tmax);
-    const int n = snprintf(buf, (size_t)buf_len, "qkv=%s;attn=%s;proj=%s;resid=k_resid_stats;resid_launches_per_step=%d;fc1=%s;fc2=%s;head=k_gemm<EPI_LOGITS,LN> (fp32 MFMA)",
-                           qkv, attn, proj, p.proj_xr ? 1 : g->L + 1, fc1, fc2);
+    const int n = snprintf(buf, (size_t)buf_len, "qkv=%s;attn=%s;proj=%s;resid=k_resid_stats;resid_launches_per_step=%d;fc1=%s;fc2=%s;head=k_gemm<EPI_LOGITS,LN> (fp32 MFMA);barrier_fallbacks=%d",
+                           qkv, attn, proj, p.proj_xr ? 1 : g->L + 1, fc1, fc2, g->fallbacks);
     WMAR_REQUIRE(n > 0 && n < buf_len, "plan_info: buffer of %lld bytes too small", (long long)buf_len);
     return WMAR_OK;
 }
@@ -810,19 +844,22 @@ int wmar_gpt_get_timing(wmar_gpt* g, double* total_us, int64_t* calls, double* s
     return WMAR_OK;
 }
 
-int wmar_gpt_generate(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_params* sp, const int64_t* cond_dev,
-                      int64_t B, int32_t steps, const float* q_dev, int64_t* tokens_out_dev,
-                      float* logits_trace_dev, void* stream) {
+static int gpt_generate_once(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_params* sp, const int64_t* cond_dev,
+                             int64_t B, int32_t steps, const float* q_dev, int64_t* tokens_out_dev,
+                             float* logits_trace_dev, void* stream) {
     WMAR_REQUIRE(g && sp && cond_dev && q_dev && tokens_out_dev, "generate: null argument");
     WMAR_REQUIRE(B >= 1 && B <= g->Bmax, "generate: batch %lld outside 1..%d", (long long)B, g->Bmax);
     WMAR_REQUIRE(steps >= 1 && steps <= g->Tmax, "generate: steps %d outside 1..block_size %d", steps, g->Tmax);
     WMAR_REQUIRE(!(sp->top_p >= 0) || sp->top_p <= 1.0, "`top_p` has to be a float > 0 and < 1, but is %f", sp->top_p);
     if (wm) {
         WMAR_REQUIRE(wm->table_dev && wm->vocab_size == g->V, "generate: watermark vocab mismatch");
-        WMAR_REQUIRE(wm->context_size >= 0 && wm->context_size <= 3, "context size unsupported");
+        WMAR_REQUIRE(wm->context_size >= 0 && wm->context_size <= WMAR_MAX_CONTEXT, "context size unsupported");
+        WMAR_REQUIRE(wm->seed_strategy != WMAR_SEED_SPATIAL || wm->context_size == 1 || wm->context_size == 3,
+                     "Spatial seeding only implemented for context size in [1,3]");
     }
     hipStream_t st = (hipStream_t)stream;
     const long long pstride = g->Tmax + 1;
+    if (int rc = gpt_inject(g, st)) return rc;
     // past[b][0] = conditioning token; position and step counters to 0
     WMAR_HIP_CHECK(hipMemcpy2DAsync(g->past, pstride * 8, cond_dev, 8, 8, (size_t)B, hipMemcpyDeviceToDevice, st));
     WMAR_HIP_CHECK(hipMemsetAsync(g->pos_dev, 0, 8, st));
@@ -916,6 +953,23 @@ int wmar_gpt_generate(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_para
         g->step_ms = ms / steps;
     }
     return WMAR_OK;
+}
+
+int wmar_gpt_generate(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_params* sp, const int64_t* cond_dev,
+                      int64_t B, int32_t steps, const float* q_dev, int64_t* tokens_out_dev,
+                      float* logits_trace_dev, void* stream) {
+    WMAR_REQUIRE(g, "generate: null argument");
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (int rc = gpt_generate_once(g, wm, sp, cond_dev, B, steps, q_dev, tokens_out_dev, logits_trace_dev, stream)) return rc;
+        // While the engine runs the fused projection launch the call waits for its replays and reads the barrier flags; a run that
+        // raised one is repeated on the two-launch path (same inputs, same noise: the same tokens).  On the two-launch path the call
+        // stays asynchronous.
+        const int f = gpt_sync_failed(g, (hipStream_t)stream);
+        if (f < 0) return f;
+        if (f == 0) return WMAR_OK;
+    }
+    set_error("generate: the in-launch barrier flag is up on the two-launch path");
+    return WMAR_EHIP;
 }
 
 }  // extern "C"

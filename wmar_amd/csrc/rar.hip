@@ -186,7 +186,12 @@ struct ResidModArgs {
 
 // KPW = k-blocks per wave: 1 for the usual widths (a chunk = 4 k-blocks: 4 x as many workgroups as k_resid_stats' 16-block chunks -- the
 // launch is bound by each workgroup's read of its slab chunk from the other XCDs' L2 / the memory-side cache), 4 beyond 2048 features.
-template <int S, int KPW>
+// PHASE 0: the fused launch described above.  PHASE 1 / 2: the same work as TWO launches, with the kernel boundary in the place of the
+// in-launch wait -- 1 folds, stores x' and publishes the partial sums; 2 re-reads its x' chunk and the (by then complete) sums and
+// modulates.  Same arithmetic and summation order: bit-identical results.  The engine falls back to this pair when a wait of the
+// fused launch gave up (rar_verify): a device that does not hold the whole grid at once.
+constexpr unsigned RM_MAX_POLLS = 1u << 16;      // ~50 ms of polling against microseconds on a healthy device
+template <int S, int KPW, int PHASE = 0>
 __global__ __launch_bounds__(256) void k_resid_mod(ResidModArgs a) {
     __shared__ double red[4][64][2];
     __shared__ double grp[8][32][2];
@@ -199,6 +204,9 @@ __global__ __launch_bounds__(256) void k_resid_mod(ResidModArgs a) {
     const int Mpad = r.MT * 32;
     const bool shared = a.shift_u && m >= a.split;
     const long long urow = (long long)(*r.pos_dev) * a.mod_stride;
+    // a wait that gave up anywhere (this launch or an earlier one of the call) ends every later wait at once: the call is repeated on
+    // the two-launch path, nobody spins through the rest of the captured loop.  (Requested here, with the operands.)
+    const unsigned fail0 = PHASE == 0 ? __hip_atomic_load(a.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     // every operand of both phases is requested before the first use
     float4 v[KPW], bb[KPW], sl[KPW][S], gg[KPW], g4[KPW], b4[KPW], sc[KPW], sh[KPW];
     int kbs[KPW];
@@ -210,9 +218,11 @@ __global__ __launch_bounds__(256) void k_resid_mod(ResidModArgs a) {
         const long long idx = ((long long)kk * r.MT + mt) * 64 + lane;
         const int k = kk * 8 + 4 * half;
         v[i] = r.x[idx];
-        bb[i] = *(const float4*)(r.bias + k);
+        if (PHASE != 2) {
+            bb[i] = *(const float4*)(r.bias + k);
 #pragma unroll
-        for (int si = 0; si < S; ++si) sl[i][si] = r.slabs[(long long)si * r.slab_stride + idx];
+            for (int si = 0; si < S; ++si) sl[i][si] = r.slabs[(long long)si * r.slab_stride + idx];
+        }
         g4[i] = a.gamma ? *(const float4*)(a.gamma + k) : make_float4(1.f, 1.f, 1.f, 1.f);
         b4[i] = a.gamma ? *(const float4*)(a.beta + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (shared) {
@@ -231,6 +241,7 @@ __global__ __launch_bounds__(256) void k_resid_mod(ResidModArgs a) {
     for (int i = 0; i < KPW; ++i) {
         rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (kbs[i] < 0) continue;
+        if (PHASE == 2) { rv[i] = v[i]; continue; }      // x' as phase 1 stored it
         float4 acc = sl[i][0];
 #pragma unroll
         for (int si = 1; si < S; ++si) { acc.x += sl[i][si].x; acc.y += sl[i][si].y; acc.z += sl[i][si].z; acc.w += sl[i][si].w; }
@@ -241,15 +252,18 @@ __global__ __launch_bounds__(256) void k_resid_mod(ResidModArgs a) {
         s += (double)x.x + (double)x.y + (double)x.z + (double)x.w;
         ss += sq4_f64(x);         // never a v_fmac_f64 chain: common.h
     }
+    constexpr unsigned long long POISON = ~0ull;
+    if (PHASE != 2) {
     red[w][lane][0] = s; red[w][lane][1] = ss;       // all 64 lanes, no shuffle (decoder_kernels.h, k_qkvx_bx's keeper reduction)
     __syncthreads();
-    constexpr unsigned long long POISON = ~0ull;
     if (w == 0 && lane < 32) {
         double ts = 0, tss = 0;
         for (int i = 0; i < 4; ++i) { ts += red[i][lane][0] + red[i][lane + 32][0]; tss += red[i][lane][1] + red[i][lane + 32][1]; }
         unsigned long long* o = a.part + ((long long)c * Mpad + mt * 32 + lane) * 2;
         __hip_atomic_store(o, (unsigned long long)__double_as_longlong(ts), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(o + 1, (unsigned long long)__double_as_longlong(tss), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (PHASE == 1) return;
     }
     {
         // row statistics of this tile's rows: thread (row = lane % 32, group = 2 w + lane / 32) re-reads the words of chunks group,
@@ -258,6 +272,7 @@ __global__ __launch_bounds__(256) void k_resid_mod(ResidModArgs a) {
         const int row = lane & 31, gq = 2 * w + (lane >> 5);
         unsigned long long t0[8], t1[8];
         unsigned spins = 0;
+        bool dead = fail0 != 0u;
         for (;;) {
             bool ok = true;
 #pragma unroll
@@ -270,9 +285,12 @@ __global__ __launch_bounds__(256) void k_resid_mod(ResidModArgs a) {
                     ok = ok && t0[i] != POISON && t1[i] != POISON;
                 }
             }
-            if (__all(ok)) break;
+            if (__all(ok) || dead) break;
+            if (PHASE == 2) { __hip_atomic_store(a.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }    // behind a kernel boundary nothing can be missing
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 20)) { *a.fail = 1u; break; }
+            ++spins;
+            if ((spins & 255u) == 0u) dead = __hip_atomic_load(a.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            if (spins > RM_MAX_POLLS) { __hip_atomic_store(a.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
         double sm = 0, sq = 0;
 #pragma unroll
@@ -305,15 +323,22 @@ __global__ __launch_bounds__(256) void k_resid_mod(ResidModArgs a) {
     }
 }
 
-static int launch_resid_mod(const ResidModArgs& a, int grid, int kpw, hipStream_t st) {
+template <int PHASE>
+static int launch_resid_mod_phase(const ResidModArgs& a, int grid, int kpw, hipStream_t st) {
     switch (a.r.S) {
-#define WMAR_RM_CASE(N) case N: if (kpw == 1) hipLaunchKernelGGL((k_resid_mod<N, 1>), dim3(grid), dim3(256), 0, st, a); \
-                                else hipLaunchKernelGGL((k_resid_mod<N, 4>), dim3(grid), dim3(256), 0, st, a); break;
+#define WMAR_RM_CASE(N) case N: if (kpw == 1) hipLaunchKernelGGL((k_resid_mod<N, 1, PHASE>), dim3(grid), dim3(256), 0, st, a); \
+                                else hipLaunchKernelGGL((k_resid_mod<N, 4, PHASE>), dim3(grid), dim3(256), 0, st, a); break;
         WMAR_RM_CASE(1) WMAR_RM_CASE(2) WMAR_RM_CASE(3) WMAR_RM_CASE(4) WMAR_RM_CASE(5) WMAR_RM_CASE(6) WMAR_RM_CASE(7) WMAR_RM_CASE(8)
 #undef WMAR_RM_CASE
         default: set_error("resid_mod: bad slab count %d", a.r.S); return WMAR_EINVAL;
     }
     return launch_status("k_resid_mod");
+}
+// fused: one launch with the in-launch wait; otherwise the two-launch pair
+static int launch_resid_mod(const ResidModArgs& a, int grid, int kpw, bool fused, hipStream_t st) {
+    if (fused) return launch_resid_mod_phase<0>(a, grid, kpw, st);
+    if (int rc = launch_resid_mod_phase<1>(a, grid, kpw, st)) return rc;
+    return launch_resid_mod_phase<2>(a, grid, kpw, st);
 }
 
 // SiLU(emb[cond] + timesteps[p]) for p = 0..T-1 in packed layout: the adaLN input of a row whose
@@ -397,6 +422,10 @@ struct wmar_rar {
     unsigned long long* part = nullptr;   // [2 L launch sites][STAT_CHUNKS_MAX][Mpad][2]: k_resid_mod's published partial sums, poisoned at the start of every position
     size_t part_site = 0;                 // words per site
     unsigned* sync_fail = nullptr;
+    bool rm_fused = true;          // k_resid_mod as ONE launch with an in-launch wait; false (WMAR_NO_XR=1, an occupancy short of the grid, or a
+                                   // wait that gave up): the two-launch pair
+    int inject_fail = 0;           // WMAR_INJECT_SYNC_FAIL=1 at creation (tests): the next fused call finds the flag raised
+    int fallbacks = 0;
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev = nullptr;
     hipGraph_t graph = nullptr;
@@ -493,7 +522,7 @@ struct RarPlan {
         if (shared_u) { a.gate_u = g->mod_u + off_gate; a.shift_u = g->mod_u + off_shift; a.scale_u = g->mod_u + off_scale; a.split = Bhalf; }
         a.h = g->h; a.hq = planes;
         a.part = g->part + (size_t)site * site_words(); a.fail = g->sync_fail;
-        return launch_resid_mod(a, nrm * MT, kpw, st);
+        return launch_resid_mod(a, nrm * MT, kpw, g->rm_fused, st);
     }
     // words of one k_resid_mod launch site at THIS plan's row count: [chunks][32 MT][2]; the sites are packed at this size, so the
     // poison memset of a position covers exactly what the launches poll
@@ -748,19 +777,17 @@ int wmar_rar_create(const wmar_rar_config* cfg, const char* const* names, const 
         // k_resid_mod's workgroups wait for each other's partial sums inside ONE launch: every workgroup of its grid (chunks x row
         // tiles, at most 64 x 4) must be resident at the same time.  Checked here against what the device can hold (the occupancy
         // the runtime reports for the widest instantiation x the compute units it exposes -- a CU mask or a partition mode shrinks
-        // it); a device that cannot is refused loudly instead of risking a stall.  A wait that gives up at run time (2^20 polls)
-        // sets sync_fail, which wmar_rar_check and every later call report.
+        // it); a device that cannot runs the two-launch pair (k_resid_mod<., ., 1> + <., ., 2>: same results) from the start.  A
+        // wait that gives up at run time raises sync_fail: the call is then repeated on the two-launch pair (rar_sync_failed).
         int nb = 0, dev = 0, cus = 0;
-        hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_resid_mod<8, 4>, 256, 0);
+        hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_resid_mod<8, 4, 0>, 256, 0);
         if (e1 == hipSuccess) e1 = hipGetDevice(&dev);
         if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const int kbd = D / 8, kpw = kbd <= 256 ? 1 : 4;
         const long long need = (long long)((kbd + 4 * kpw - 1) / (4 * kpw)) * g->MTmax;
         if (e1 != hipSuccess) { set_error("rar_create: occupancy query failed: %s", hipGetErrorString(e1)); rc = WMAR_EHIP; }
-        else if ((long long)nb * cus < need) {
-            set_error("rar_create: the fused residual + modulation launch needs %lld co-resident workgroups, the device holds %d x %d", need, nb, cus);
-            rc = WMAR_EINVAL;
-        }
+        else g->rm_fused = (long long)nb * cus >= need && getenv("WMAR_NO_XR") == nullptr;
+        { const char* e = getenv("WMAR_INJECT_SYNC_FAIL"); g->inject_fail = (e && atoi(e) > 0) ? 1 : 0; }
     }
     if (rc == WMAR_OK) {
         hipError_t er = hipMemsetAsync(g->x, 0, Mpad * D * 4, st);
@@ -786,21 +813,44 @@ int wmar_rar_create(const wmar_rar_config* cfg, const char* const* names, const 
 
 void wmar_rar_destroy(wmar_rar* g) { delete g; }
 
-// The in-launch waits of k_resid_mod raise g->sync_fail when they give up; the results of that call are then invalid.
-static int rar_sync_status(wmar_rar* g, hipStream_t st) {
+// The in-launch waits of k_resid_mod raise g->sync_fail when they give up.  Returns 1 when the flag was up: the engine has then been
+// switched to the two-launch pair, its graph dropped and the flag cleared -- the caller repeats its work (deterministic in its
+// inputs).  0: clean.  < 0: HIP error.
+static int rar_sync_failed(wmar_rar* g, hipStream_t st) {
+    if (!g->rm_fused) return 0;
     unsigned f = 0;
     WMAR_HIP_CHECK(hipMemcpyAsync(&f, g->sync_fail, 4, hipMemcpyDeviceToHost, st));
     WMAR_HIP_CHECK(hipStreamSynchronize(st));
-    if (f) {
-        (void)hipMemsetAsync(g->sync_fail, 0, 4, st);
-        set_error("rar: an in-launch wait of k_resid_mod gave up (its workgroups were not co-resident): the results of the previous call are invalid");
+    if (!f) return 0;
+    g->drop_graph();
+    WMAR_HIP_CHECK(hipMemsetAsync(g->sync_fail, 0, 4, st));
+    g->rm_fused = false;
+    g->fallbacks += 1;
+    return 1;
+}
+static int rar_inject(wmar_rar* g, hipStream_t st) {
+    if (!g->inject_fail || !g->rm_fused) return WMAR_OK;
+    g->inject_fail = 0;
+    hipLaunchKernelGGL(k_set3, dim3(1), dim3(1), 0, st, (int*)g->sync_fail, 1, 0, 0);
+    return launch_status("k_set3");
+}
+int wmar_rar_check(wmar_rar* g, void* stream) {
+    WMAR_REQUIRE(g, "rar_check: null argument");
+    // generate / forward_position verify and recover by themselves; kept for callers that want to know whether the fused launch still runs
+    const int f = rar_sync_failed(g, (hipStream_t)stream);
+    if (f < 0) return f;
+    if (f > 0) {
+        set_error("rar: an in-launch wait of k_resid_mod gave up (its workgroups were not co-resident): the launches since the last check "
+                  "are invalid (the engine continues on the two-launch pair)");
         return WMAR_EHIP;
     }
     return WMAR_OK;
 }
-int wmar_rar_check(wmar_rar* g, void* stream) {
-    WMAR_REQUIRE(g, "rar_check: null argument");
-    return rar_sync_status(g, (hipStream_t)stream);
+int wmar_rar_launch_status(const wmar_rar* g, int32_t* fused, int32_t* fallbacks) {
+    WMAR_REQUIRE(g, "rar_launch_status: null argument");
+    if (fused) *fused = g->rm_fused ? 1 : 0;
+    if (fallbacks) *fallbacks = g->fallbacks;
+    return WMAR_OK;
 }
 int64_t wmar_rar_device_bytes(const wmar_rar* g) { return g ? g->mem.bytes : 0; }
 
@@ -810,13 +860,23 @@ int wmar_rar_forward_position(wmar_rar* g, const int64_t* tok_dev, const int64_t
     WMAR_REQUIRE(M >= 1 && M <= g->Mmax, "rar_forward_position: rows %lld outside 1..%d", (long long)M, g->Mmax);
     WMAR_REQUIRE(pos >= 0 && pos < g->T, "rar_forward_position: position %d outside 0..%d", pos, g->T - 1);
     hipStream_t st = (hipStream_t)stream;
-    WMAR_HIP_CHECK(hipMemcpyAsync(g->cond_ids, cond_ids_dev, (size_t)M * 8, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(k_set3, dim3(1), dim3(1), 0, st, g->ctr, (int)pos, 0, 0);
-    RarPlan p(g, (int)M, (int)M, (const long long*)tok_dev, st);
-    return p.position(true, logits_dev);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (int rc = rar_inject(g, st)) return rc;
+        WMAR_HIP_CHECK(hipMemcpyAsync(g->cond_ids, cond_ids_dev, (size_t)M * 8, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_set3, dim3(1), dim3(1), 0, st, g->ctr, (int)pos, 0, 0);
+        RarPlan p(g, (int)M, (int)M, (const long long*)tok_dev, st);
+        if (int rc = p.position(true, logits_dev)) return rc;
+        // on the fused path the call waits for the position and checks the in-launch waits; a failed position is repeated on the
+        // two-launch pair (a pure function of the tokens, the position and the cache rows below it)
+        const int f = rar_sync_failed(g, st);
+        if (f < 0) return f;
+        if (f == 0) return WMAR_OK;
+    }
+    set_error("rar_forward_position: the in-launch wait flag is up on the two-launch pair");
+    return WMAR_EHIP;
 }
 
-static int rar_generate_impl(wmar_rar* g, const wmar_wm_ctx* wm, const int64_t* class_ids_dev, int64_t B,
+static int rar_generate_once(wmar_rar* g, const wmar_wm_ctx* wm, const int64_t* class_ids_dev, int64_t B,
                              const float* cfg_scale_host, int32_t use_guidance, float temperature, const float* q_dev,
                              const float* log_rs_dev, float top_p, int32_t top_k,
                              int64_t* tokens_out_dev, int32_t use_graph, void* stream) {
@@ -828,6 +888,7 @@ static int rar_generate_impl(wmar_rar* g, const wmar_wm_ctx* wm, const int64_t* 
     const int L = g->cfg.image_seq_len, V = g->V;
     const int M = use_guidance ? 2 * (int)B : (int)B;
     g->drop_graph();
+    if (int rc = rar_inject(g, st)) return rc;
     // condition ids: class + codebook_size + 1, unconditional rows get the "none" id (rar.py:303-312)
     std::vector<long long> hc((size_t)B);
     WMAR_HIP_CHECK(hipMemcpyAsync(hc.data(), class_ids_dev, (size_t)B * 8, hipMemcpyDeviceToHost, st));
@@ -906,6 +967,24 @@ static int rar_generate_impl(wmar_rar* g, const wmar_wm_ctx* wm, const int64_t* 
             if (int rc = one_step(st)) return rc;
     }
     return WMAR_OK;
+}
+
+static int rar_generate_impl(wmar_rar* g, const wmar_wm_ctx* wm, const int64_t* class_ids_dev, int64_t B,
+                             const float* cfg_scale_host, int32_t use_guidance, float temperature, const float* q_dev,
+                             const float* log_rs_dev, float top_p, int32_t top_k,
+                             int64_t* tokens_out_dev, int32_t use_graph, void* stream) {
+    WMAR_REQUIRE(g, "rar_generate: null argument");
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (int rc = rar_generate_once(g, wm, class_ids_dev, B, cfg_scale_host, use_guidance, temperature, q_dev, log_rs_dev, top_p, top_k,
+                                       tokens_out_dev, use_graph, stream)) return rc;
+        // on the fused path the call waits for its replays and reads the wait flag; a run that raised it is repeated on the
+        // two-launch pair (same inputs, same noise: the same tokens)
+        const int f = rar_sync_failed(g, (hipStream_t)stream);
+        if (f < 0) return f;
+        if (f == 0) return WMAR_OK;
+    }
+    set_error("rar_generate: the in-launch wait flag is up on the two-launch pair");
+    return WMAR_EHIP;
 }
 
 int wmar_rar_generate(wmar_rar* g, const wmar_wm_ctx* wm, const int64_t* class_ids_dev, int64_t B,

@@ -533,23 +533,35 @@ __global__ __launch_bounds__(256) void k_detect(DetArgs a) {
     if (mask)
         for (int i = threadIdx.x; i < h; i += blockDim.x) mask[i] = -1;
     int ns = 0, ng = 0;
+    const bool spatial = a.wm.seed_mode == WMAR_SEED_SPATIAL;       // (h + 1)-grams of at most 4 cells; LINEAR / FIXED: any h, consecutive
     for (long long i = threadIdx.x; i < cnt; i += blockDim.x) {
         long long pi[4], pj[4], ti[4];
-        det_ngram_pos(a.wm.seed_mode, h, S, i, pi);
-        for (int k = 0; k < n; ++k) ti[k] = codes[pi[k]];
         bool dup = false;
-        for (long long j = 0; j < i && !dup; ++j) {
-            det_ngram_pos(a.wm.seed_mode, h, S, j, pj);
-            bool same = true;
-            for (int k = 0; k < n; ++k) same = same && (codes[pj[k]] == ti[k]);
-            dup = same;
+        long long sum = 0, tgt;
+        if (spatial) {
+            det_ngram_pos(a.wm.seed_mode, h, S, i, pi);
+            for (int k = 0; k < n; ++k) ti[k] = codes[pi[k]];
+            for (long long j = 0; j < i && !dup; ++j) {
+                det_ngram_pos(a.wm.seed_mode, h, S, j, pj);
+                bool same = true;
+                for (int k = 0; k < n; ++k) same = same && (codes[pj[k]] == ti[k]);
+                dup = same;
+            }
+            for (int k = 0; k < h; ++k) sum += ti[k];
+            tgt = ti[h];
+        } else {
+            // the i-th n-gram is codes[i .. i + h] (gentime_watermark.py:33-44): no position arrays, any context size
+            for (long long j = 0; j < i && !dup; ++j) {
+                bool same = true;
+                for (int k = 0; k < n && same; ++k) same = codes[j + k] == codes[i + k];
+                dup = same;
+            }
+            for (int k = 0; k < h; ++k) sum += codes[i + k];
+            tgt = codes[i + h];
         }
         int g = 0;
         if (!dup) {
-            long long sum = 0;
-            for (int k = 0; k < h; ++k) sum += ti[k];
             long long row = a.wm.seed_mode == WMAR_SEED_FIXED ? 0 : sum;
-            long long tgt = ti[h];
             if (row >= 0 && row < a.wm.n_rows && tgt >= 0 && tgt < a.wm.row_words * 32)
                 g = (a.wm.table[row * a.wm.row_words + (tgt >> 5)] >> (tgt & 31)) & 1u;
             ns += 1;
@@ -590,7 +602,9 @@ static int check_wm(const wmar_wm_ctx* wm, int64_t V) {
     if (wm->seed_strategy == WMAR_SEED_SPATIAL)
         WMAR_REQUIRE(wm->context_size == 1 || wm->context_size == 3,
                      "Spatial seeding only implemented for context size in [1,3]");
-    WMAR_REQUIRE(wm->context_size >= 0 && wm->context_size <= 3, "context size %d unsupported (0..3)", wm->context_size);
+    // LINEAR / FIXED: any context size (gentime_watermark.py:236-241); the key table has context_size * (V - 1) + 1 rows
+    WMAR_REQUIRE(wm->context_size >= 0 && wm->context_size <= WMAR_MAX_CONTEXT, "context size %d unsupported (0..%d)", wm->context_size,
+                 WMAR_MAX_CONTEXT);
     return WMAR_OK;
 }
 

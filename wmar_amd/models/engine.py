@@ -213,6 +213,12 @@ class RAREngine:
     def device_bytes(self) -> int:
         return int(self._L.wmar_rar_device_bytes(self._h))
 
+    def launch_status(self) -> Dict[str, int]:
+        """{"fused": the fused residual + modulation launch is in use, "fallbacks": calls re-run on the two-launch pair}."""
+        a, b = C.c_int32(), C.c_int32()
+        _lib.check(self._L.wmar_rar_launch_status(self._h, C.byref(a), C.byref(b)))
+        return {"fused": int(a.value), "fallbacks": int(b.value)}
+
     def forward_position(self, tok: torch.Tensor, cond_ids: torch.Tensor, pos: int) -> torch.Tensor:
         """tok int64 [M] (-1 = cls), cond_ids int64 [M] (offset condition ids) -> logits [M, V]."""
         _require_cuda(tok, "tokens")

@@ -39,6 +39,7 @@ class SplitStrategy(Enum):
     CLUSTERING = "clustering"
 
 
+MAX_CONTEXT = 16      # include/wmar_hip.h WMAR_MAX_CONTEXT (LINEAR / FIXED; SPATIAL: 1 or 3 as in the reference)
 _SEED_CODE = {SeedStrategy.FIXED: 0, SeedStrategy.LINEAR: 1, SeedStrategy.SPATIAL: 2}
 _SPLIT_CODE = {SplitStrategy.RANDOM: 0, SplitStrategy.RANDOM_STRATIFIED: 1}
 
@@ -105,8 +106,8 @@ class GentimeWatermark:
             raise NotImplementedError("SplitStrategy.CLUSTERING (TSNE+KMeans split) is outside the MI355X hot path")
         if seed_strategy is SeedStrategy.SPATIAL and context_size not in (1, 3):
             raise AssertionError("Spatial seeding only implemented for context size in [1,3]")
-        if not 0 <= context_size <= 3:
-            raise NotImplementedError("context sizes 0..3 are supported")
+        if not 0 <= context_size <= MAX_CONTEXT:
+            raise NotImplementedError(f"context sizes 0..{MAX_CONTEXT} are supported (the key table has context_size * (vocab - 1) + 1 rows)")
         self._table = None
         if self.seed_strategy == SeedStrategy.FIXED:
             self.fixed_greenlist = self._split_with_seed(0)
