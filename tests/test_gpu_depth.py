@@ -8,7 +8,7 @@ summation-order error over 48 residual blocks and the weight-pack offsets of the
     tests/test_oracle_golden.py pins it to the incremental path): 64 rows (the benchmark's batch: k_qkvx_bx, k_bx_xr, k_fc1x and
     their per-layer packed weights) at positions 0, 1, 39, and 8 rows (the small-batch kernels, 2 / 4 attention waves) at
     positions 113, 255 (long caches); the arg-max of every row equal;
-    (b) a 64-row x 48-step watermarked sampling loop (greenlist delta 2, top-k 250, top-p 0.92), graph and eager, token for
+    (b) a 64-row x 32-step watermarked sampling loop (greenlist delta 2, top-k 250, top-p 0.92), graph and eager, token for
     token against `model_oracle.sample_with_past` (mingpt.py:326-368) on the same noise.
   * RAR-XL: 64 conditions under guidance (128 rows, the benchmark's batch), the first 12 tokens of RAR.generate
     (rar.py:408-459) against `rar_oracle.generate`, and the logits of those positions.
@@ -99,7 +99,7 @@ def test_taming_48_layers_watermarked_loop_tokens(gpt48, kat, key_factory):
     cfg = synth.TAMING_GPT
     wm = _wm(kat["keys"]["taming"])
     key = key_factory(kat["keys"]["taming"])
-    B, steps = 64, 48
+    B, steps = 64, 32
     cond = torch.tensor([(i * 37 + 3) % 1000 for i in range(B)])
     g = torch.Generator().manual_seed(4848)
     q = torch.empty(steps, B, cfg.vocab_size).exponential_(1, generator=g)
