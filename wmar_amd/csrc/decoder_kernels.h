@@ -1068,6 +1068,7 @@ __device__ __forceinline__ double qx_sq4_exp(const float4& r) {
 #define WMAR_QX_SQ4(R) sq4_f64(R)
 #endif
 
+constexpr int QX_TR_STRIDE = 36;      // floats per row of the epilogue's transpose tile (32 + 4: 16-byte rows on distinct banks)
 template <int S_IN>
 __global__ __launch_bounds__(512) void k_qkvx_bx(QkvxArgs a) {
     constexpr int MTW = 2;
@@ -1075,6 +1076,7 @@ __global__ __launch_bounds__(512) void k_qkvx_bx(QkvxArgs a) {
     asm volatile(".rept " WMAR_STR(QX_PAD) "\n\ts_nop 0\n\t.endr");      // dev: shifts the kernel's code by 4 QX_PAD bytes (scripts/fmac_experiment.sh)
 #endif
     __shared__ __attribute__((aligned(16))) u32x4 xq[2][2][MTW][3][64];      // [buffer][step][row tile][piece][lane]
+    __shared__ __attribute__((aligned(16))) float tr_s[4][32 * QX_TR_STRIDE];   // epilogue: one 32 x 32 tile per multiplying wave
 #ifdef QX_OLD_RED
     __shared__ double red[4][MTW][32][2];      // dev experiment: the round-2 reduction (64-bit __shfl_xor + lanes 0..31 publish)
 #else
@@ -1268,13 +1270,31 @@ __global__ __launch_bounds__(512) void k_qkvx_bx(QkvxArgs a) {
 #undef WMAR_QX_MFMA
 #undef WMAR_QX_BF
 #undef WMAR_QX_STEP
-    // one split-K piece per wave, straight from the accumulators (already the packed layout of the consumer)
+    // One split-K piece per wave, ROW-MAJOR (round 5): piece s is [64 rows][3 D] floats, so the attention workgroup of (sequence,
+    // head) finds its q / k / v columns of a piece as 256 contiguous bytes.  In the packed operand layout the same 64 floats lay in
+    // 16 different 128-byte lines shared with 31 other sequences: the attention prologue touched 384 lines (49 KB) per wave for
+    // 5.4 KB of payload -- 75 MB of L2 -> L1 traffic per launch beside the 100 MB of K/V it streams.  The accumulators (row = lane % 32,
+    // columns 8 q4 + 4 (lane / 32) ..+3 of the wave's 32-column tile) are turned through a wave-private LDS tile: a store instruction
+    // then covers eight rows x 128 contiguous bytes.
 #pragma unroll
-    for (int i = 0; i < MTW; ++i)
+    for (int i = 0; i < MTW; ++i) {
+        float* T = &tr_s[w][0];
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4)
-            st_out(a.out + (long long)s * a.out_stride + ((long long)(nt * 4 + q4) * MTW + i) * 64 + lane,
-                   make_float4(acc[i][q4 * 4 + 0], acc[i][q4 * 4 + 1], acc[i][q4 * 4 + 2], acc[i][q4 * 4 + 3]));
+            *(float4*)(T + (lane & 31) * QX_TR_STRIDE + 8 * q4 + 4 * half) =
+                make_float4(acc[i][q4 * 4 + 0], acc[i][q4 * 4 + 1], acc[i][q4 * 4 + 2], acc[i][q4 * 4 + 3]);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = (lane >> 3) + 8 * it, cg = lane & 7;
+            const float4 v = *(const float4*)(T + row * QX_TR_STRIDE + 4 * cg);
+            // piece s starts at out + s * out_stride (float4 units; the same size as a packed piece), row m at m * 3 D floats
+            st_out(a.out + (long long)s * a.out_stride + ((long long)(32 * i + row) * (a.NT * 32) + nt * 32 + 4 * cg) / 4, v);
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     if (keeper) __syncthreads();
 }
 
@@ -1654,6 +1674,7 @@ struct AttnArgs {
     double invK;               // 1 / K (host-computed: a double division costs the prologue ~100 cycles)
     const float* c1;           // [3D] row sums of the gamma-folded QKV weights (mode 0)
     const float* bias;         // [3D] bias (+ W beta in mode 0)
+    int rowmajor;              // the pieces are row-major [rows][3 D] (written by k_qkvx_bx) instead of the packed operand layout
     int mode;                  // 0: minGPT (LN1 folded, finish with LN algebra); 1: RAR (plain bias, then per-head
                                //    LayerNorm of q and k -- Attention.q_norm / k_norm, rar.py:76-94)
     const float *qn_w, *qn_b, *kn_w, *kn_b;   // [hd] (mode 1)
@@ -1738,7 +1759,9 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
 #pragma unroll
     for (int which = 0; which < 3; ++which) {
         const int n = which * a.D + h * HD + sub * 4;          // first of this lane's 4 columns
-        const long long idx = ((long long)(n >> 3) * a.MT + mt) * 64 + (b & 31) + 32 * ((n >> 2) & 1);
+        // packed operand layout, or row-major pieces [rows][3 D] (k_qkvx_bx, round 5): this lane's float4 of row b
+        const long long idx = a.rowmajor ? ((long long)b * (3 * a.D) + n) >> 2
+                                         : ((long long)(n >> 3) * a.MT + mt) * 64 + (b & 31) + 32 * ((n >> 2) & 1);
         if (w == 0) {           // wave-uniform
 #pragma unroll
             for (int pi = 0; pi < PMAX; ++pi) {
@@ -1995,7 +2018,9 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode80(AttnArgs a) {
 #pragma unroll
     for (int which = 0; which < 3; ++which) {
         const int n = which * a.D + h * HD + sub * 4;          // first of this lane's 4 columns
-        const long long idx = ((long long)(n >> 3) * a.MT + mt) * 64 + (b & 31) + 32 * ((n >> 2) & 1);
+        // packed operand layout, or row-major pieces [rows][3 D] (k_qkvx_bx, round 5): this lane's float4 of row b
+        const long long idx = a.rowmajor ? ((long long)b * (3 * a.D) + n) >> 2
+                                         : ((long long)(n >> 3) * a.MT + mt) * 64 + (b & 31) + 32 * ((n >> 2) & 1);
         if (w == 0) {           // wave-uniform
 #pragma unroll
             for (int pi = 0; pi < PMAX; ++pi) {

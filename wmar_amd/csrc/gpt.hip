@@ -310,6 +310,7 @@ struct StepPlan {
         if (S_qx > 0) { t.S = S_qx; t.stats = g->stats_q; t.n_chunks = S_qx; }
         else { t.S = S_qkv; t.stats = g->stats; t.n_chunks = nch; }
         t.c1 = w.cqkv; t.bias = w.bqkv;
+        t.rowmajor = qkv_bx() ? 1 : 0;      // k_qkvx_bx writes its pieces row-major (decoder_kernels.h)
         t.kcache = g->kcache + l * lstride; t.vcache = g->vcache + l * lstride; t.y = g->y; t.yq = proj_bx ? g->yq : nullptr; t.pos_dev = g->pos_dev;
         t.D = D; t.H = g->H; t.Tmax = g->Tmax; t.MT = MT; t.scale = 1.0f / sqrtf((float)g->hd);
         int nwa = g->att_nw;   // chosen per phase by the caller (generate / profile_role)
