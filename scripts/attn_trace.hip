@@ -12,6 +12,7 @@ int main(int argc, char** argv) {
     const int D = 1536, H = 24, B = 64, MT = 2, Tmax = 256, S = argc > 2 ? atoi(argv[2]) : 7;
     const int T = argc > 1 ? atoi(argv[1]) : 128;
     const int NL = 8;
+    const int RM = argc > 3 ? atoi(argv[3]) : 1;
     hipStream_t st; hipStreamCreate(&st);
     const size_t kv = (size_t)B * H * Tmax * 64;
     std::vector<float*> K(NL), V(NL);
@@ -28,13 +29,14 @@ int main(int argc, char** argv) {
     hipMalloc(&tr, (size_t)nwg * 5 * 8);
     AttnArgs t{};
     t.qkv_slabs = pieces; t.slab_stride = (long long)act3; t.S = S; t.stats = stats; t.n_chunks = S; t.K = D; t.invK = 1.0 / (double)D; t.c1 = c1; t.bias = bias;
-    t.y = y; t.pos_dev = pos; t.D = D; t.H = H; t.Tmax = Tmax; t.MT = MT; t.scale = 0.125f; t.trace = tr;
+    t.rowmajor = RM; t.y = y; t.pos_dev = pos; t.D = D; t.H = H; t.Tmax = Tmax; t.MT = MT; t.scale = 0.125f; t.trace = tr;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0, st);
         for (int l = 0; l < NL; ++l) {
             t.kcache = K[l]; t.vcache = V[l];
-            hipLaunchKernelGGL((k_attn_decode<64, 1, false>), dim3(nwg), dim3(64), 0, st, t);
+            if (RM) hipLaunchKernelGGL((k_attn_decode<64, 1, false, 0, true>), dim3(nwg), dim3(64), 0, st, t);
+            else hipLaunchKernelGGL((k_attn_decode<64, 1, false, 0, false>), dim3(nwg), dim3(64), 0, st, t);
         }
         hipEventRecord(e1, st);
         hipStreamSynchronize(st);
@@ -49,6 +51,9 @@ int main(int argc, char** argv) {
             unsigned long long d = h[(size_t)i * 5 + k + 1] - h[(size_t)i * 5 + k];
             a[k] += d; mx[k] = std::max(mx[k], d);
         }
+    unsigned long long t0 = ~0ull, t0x = 0, t4 = 0, t4n = ~0ull;
+    for (int i = 0; i < nwg; ++i) { t0 = std::min(t0, h[(size_t)i * 5]); t0x = std::max(t0x, h[(size_t)i * 5]); t4 = std::max(t4, h[(size_t)i * 5 + 4]); t4n = std::min(t4n, h[(size_t)i * 5 + 4]); }
+    printf("rowmajor %d: first wave in at 0, last wave in at %llu, first wave out at %llu, last wave out at %llu cycles\n", RM, t0x - t0, t4n - t0, t4 - t0);
     printf("cycles avg (max): prologue loads %.0f (%llu) | finish q/k/v + barrier %.0f (%llu) | stream %.0f (%llu) | reduce + store %.0f (%llu)\n",
            a[0] / nwg, mx[0], a[1] / nwg, mx[1], a[2] / nwg, mx[2], a[3] / nwg, mx[3]);
     return 0;

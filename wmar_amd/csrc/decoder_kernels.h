@@ -36,6 +36,33 @@ __device__ __forceinline__ float2 ld_nt2(const float2* p) {
     return make_float2(v.x, v.y);
 }
 
+// ------------------------------------------------------------------------ in-loop timeline stamps (dev builds: -DWMAR_STAMPS)
+// Wave 0 of every workgroup of the five per-layer launches records eight 64-bit stamps into its launch's slot of a trace buffer
+// (StepPlan sets the pointers when the engine was created with WMAR_STAMPS=1; scripts/stamp_table.py turns them into the per-launch
+// table of DESIGN section 6): [0] s_memrealtime at entry (100 MHz, chip-wide: gaps BETWEEN launches), [1] s_memtime at entry,
+// [2] first operands landed, [3] main loop done, [4] exit (stores issued and acknowledged), [5] s_memrealtime at exit, [6] a kernel-
+// specific mark (k_bx_xr: barrier passed; attention: q/k/v finished), [7] the XCC id.  The "landed" stamp waits for the first loads
+// with s_waitcnt vmcnt(0): a diagnostic build, a few percent slower than the product.
+#ifdef WMAR_STAMPS
+#define WMAR_ST_BEGIN unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; st_[0] = __builtin_amdgcn_s_memrealtime(); st_[1] = __builtin_amdgcn_s_memtime();
+#define WMAR_ST(I) { asm volatile("" ::: "memory"); st_[I] = __builtin_amdgcn_s_memtime(); }
+#define WMAR_ST_LANDED(I) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st_[I] = __builtin_amdgcn_s_memtime(); }
+#define WMAR_ST_END(PTR, UNIT)                                                                          \
+    if ((PTR) && threadIdx.x == 0) {                                                                    \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+        st_[4] = __builtin_amdgcn_s_memtime(); st_[5] = __builtin_amdgcn_s_memrealtime();               \
+        unsigned xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_)); st_[7] = xcc_ & 15u; \
+        unsigned long long* o_ = (PTR) + (long long)(UNIT) * 8;                                         \
+        for (int i_ = 0; i_ < 8; ++i_) o_[i_] = st_[i_];                                                \
+    }
+#else
+#define WMAR_ST_BEGIN
+#define WMAR_ST(I)
+#define WMAR_ST_LANDED(I)
+#define WMAR_ST_END(PTR, UNIT)
+#endif
+constexpr int WMAR_STAMP_UNITS = 1536;     // workgroup slots per launch in the stamp buffer (the attention's grid at 64 rows x 24 heads)
+
 constexpr int MAX_SLABS = 8;
 constexpr int QKV_SLABS_MAX = 8;   // the QKV projection arrives in at most 8 split-K pieces
 constexpr int STAT_CHUNKS_MAX = 64;   // n_embd <= 8192
@@ -287,6 +314,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
         kb1 = kb0 + (u1 - u0) * 2 * U;
     }
     const int half = lane >> 5;
+    WMAR_ST_BEGIN
 #ifdef WMAR_GEMM_TRACE
     unsigned long long tr0 = __builtin_amdgcn_s_memtime(), tr1 = 0, tr2 = 0;
 #endif
@@ -367,6 +395,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
         // LayerNorm statistics are fetched AFTER the first operand loads are in flight
         WMAR_LN_PROLOGUE
         __builtin_amdgcn_sched_barrier(0);
+        WMAR_ST_LANDED(2)
 #ifdef WMAR_GEMM_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tr1 = __builtin_amdgcn_s_memtime();
@@ -442,6 +471,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
 #undef WMAR_LOAD
 #undef WMAR_MMA
 
+    WMAR_ST(3)
 #ifdef WMAR_GEMM_TRACE
     tr2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -511,6 +541,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs a) {
             if (m < a.B) *(float4*)(a.logits + (long long)m * a.V + n) = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
+    WMAR_ST_END(a.trace, blockIdx.x)
 #ifdef WMAR_GEMM_TRACE
     if (a.trace && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -655,6 +686,7 @@ static __global__ __launch_bounds__(256) void k_fc1x(Fc1xArgs a) {
         }                                                                                         \
     }
 
+    WMAR_ST_BEGIN
 #ifdef WMAR_FX_TRACE
     const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -665,6 +697,7 @@ static __global__ __launch_bounds__(256) void k_fc1x(Fc1xArgs a) {
     float mu, rstd;       // LayerNorm statistics of row = lane, fetched behind the first operands
     ln_row_stats(a.stats, a.n_chunks, 64, lane, a.K, &mu, &rstd);
     __builtin_amdgcn_sched_barrier(0);
+    WMAR_ST_LANDED(2)
 #ifdef WMAR_FX_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long tr1 = __builtin_amdgcn_s_memtime();
@@ -685,6 +718,7 @@ static __global__ __launch_bounds__(256) void k_fc1x(Fc1xArgs a) {
 #undef WMAR_FX_MMA
 #undef WMAR_FX_UNIT
 
+    WMAR_ST(3)
 #ifdef WMAR_FX_TRACE
     const unsigned long long tr2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -727,6 +761,7 @@ static __global__ __launch_bounds__(256) void k_fc1x(Fc1xArgs a) {
         o[2] = gelu_erf(rs * (o[2] - mm * cc.z) + bb.z); o[3] = gelu_erf(rs * (o[3] - mm * cc.w) + bb.w);
         st_out(a.out + ((long long)(n >> 3) * 2 + (m >> 5)) * 64 + (m & 31) + 32 * ((n >> 2) & 1), make_float4(o[0], o[1], o[2], o[3]));
     }
+    WMAR_ST_END(a.trace, blockIdx.x)
 #ifdef WMAR_FX_TRACE
     if (a.trace && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1197,6 +1232,7 @@ __global__ __launch_bounds__(512) void k_qkvx_bx(QkvxArgs a) {
     }
 
     // ------------------------------------------------------------------------------------------ multiplying waves
+    WMAR_ST_BEGIN
     const int nt = g * 4 + w;
     f32x16 acc[MTW];
 #pragma unroll
@@ -1254,6 +1290,7 @@ __global__ __launch_bounds__(512) void k_qkvx_bx(QkvxArgs a) {
     WMAR_QX_W(w1, 1)
     WMAR_QX_W(w2, 2)
     __syncthreads();                                       // barrier(-1)
+    WMAR_ST_LANDED(2)                                      // chunk 0 staged (the stagers' first loads) and this wave's first weights
     WMAR_QX_READ(xfA, 0)
     for (int c = 0; c < nch; c += 4) {
         WMAR_QX_STEP(c, w0, w3, xfA, xfB, 1)
@@ -1264,6 +1301,7 @@ __global__ __launch_bounds__(512) void k_qkvx_bx(QkvxArgs a) {
         if (c + 3 >= nch) break;
         WMAR_QX_STEP(c + 3, w3, w2, xfB, xfA, 0)
     }
+    WMAR_ST(3)
 #undef WMAR_QX_W
 #undef WMAR_QX_READ
 #undef WMAR_QX_MMA
@@ -1295,6 +1333,7 @@ __global__ __launch_bounds__(512) void k_qkvx_bx(QkvxArgs a) {
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    WMAR_ST_END(a.trace, j)
     if (keeper) __syncthreads();
 }
 
@@ -1462,6 +1501,7 @@ struct BxrArgs {
     unsigned* sync;            // [8][64] words: word 0 arrivals, word 16 the group's XCC id, word 32 generation
     unsigned* fail;            // [0] placement mismatch, [1] barrier timeout
     int tiles_per_group;       // column tiles per XCD group (N / 32 / 8)
+    unsigned long long* trace; // dev only (WMAR_STAMPS): 8 stamps per workgroup
 };
 
 // the current value of a word as THIS XCD's L2 holds it (a compiler-level fetch_or(0) folds into a load that may hit the L1)
@@ -1502,6 +1542,7 @@ __global__ __launch_bounds__(256) void k_bx_xr(BxrArgs q) {
     const int grp = (int)blockIdx.x & 7, c = (int)blockIdx.x >> 3;          // XCD group, member
     const int tile = grp * q.tiles_per_group + c / S, ks = c % S;
     unsigned gen0 = 0, xid = 0;
+    WMAR_ST_BEGIN
     if (threadIdx.x == 0) {
         xid = xcc_id();
         if (c == 0) l2_swap_u32_noret(q.sync + grp * 64 + 16, xid);
@@ -1524,6 +1565,7 @@ __global__ __launch_bounds__(256) void k_bx_xr(BxrArgs q) {
         WMAR_BXR_LOADW(0);
         WMAR_BXR_LOADX(0);
         __builtin_amdgcn_sched_barrier(0);
+        WMAR_ST_LANDED(2)
         bf16x8 ph[2], pm[2], pl[2];
         bx_split8(wr[0], wr[1], ph[0], pm[0], pl[0]);
         if (1 < PER) WMAR_BXR_LOADW(1);
@@ -1570,6 +1612,7 @@ __global__ __launch_bounds__(256) void k_bx_xr(BxrArgs q) {
     }
     // ---------------------------------------------------------------------------------------------------- XCD-local barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's slab stores are in the L2
+    WMAR_ST(3)
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned* cnt = q.sync + grp * 64;
@@ -1599,8 +1642,9 @@ __global__ __launch_bounds__(256) void k_bx_xr(BxrArgs q) {
         if (l2_read_u32(q.sync + grp * 64 + 16) != xid) __hip_atomic_store(q.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+    WMAR_ST(6)
     // ---------------------------------------------------------------------------------------------------- phase 2
-    if (c >= 2 * MTW) return;
+    if (c >= 2 * MTW) { WMAR_ST_END(q.trace, blockIdx.x) return; }
     {
         // four workgroups fold: row tile mt = c & 1, half hp = c >> 1 of the group's k-blocks (12 of 24 at n_embd 1536: three per
         // wave, ONE batch of 3 x (1 + S) loads) -> statistics chunk 2 grp + hp of 16
@@ -1643,6 +1687,7 @@ __global__ __launch_bounds__(256) void k_bx_xr(BxrArgs q) {
             o[0] = ts; o[1] = tss;
         }
     }
+    WMAR_ST_END(q.trace, blockIdx.x)
 }
 
 template <int PER, int S>
@@ -1656,6 +1701,20 @@ static int launch_bx_xr(const BxrArgs& q, int N, hipStream_t st) {
 // are loaded NON-TEMPORALLY -- round 4, same-box A/B over the 256-step loop: 4.112 -> 3.98 ms per step (Taming), 3.948 -> 3.899 (RAR-XL):
 // with plain loads 100 MB of K/V per layer swept the slabs, pieces and activations of the neighbouring launches out of the L2s.
 // -DWMAR_ATT_PLAIN_KV restores plain loads.
+// 1-KiB loads of K (and of V) per chunk of k_attn_decode.  Round 5: 2 (8 cached rows of head_dim 64 per chunk, two chunks = 8 KiB in
+// flight per wave) instead of 8.  With 32 KiB in flight per wave the 1536 waves of a 64-row launch had 50 MB queued at the memory
+// system -- four times what 6 TB/s x its latency can use -- so every dependent round of a wave waited ~8 us, some waves far longer
+// (in-loop stamps: streaming phase 9.6 us mean / 14.8 max, last workgroup out 4 us after the mean).  Same-box round-robin A/B over
+// the 256-step loop (scripts/ab_loop.py, 12 runs each): CH 8 / 4 / 3 / 2 / 1 = 3.894 / 3.851 / 3.840 / 3.798 / 3.829 ms per step.
+#ifndef WMAR_ATT_CH
+#define WMAR_ATT_CH 2
+#endif
+// Order of the first requests of a one-wave workgroup (LATE in k_attn_decode): 0 = first chunk requested together with the prologue's
+// operands (round 4), 1 = both chunks once the operands are here, 2 = first chunk once they are here, the second behind the q / k / v
+// algebra.  At CH 2 the three are within noise (3.798 / 3.814 / 3.798); at CH 8: 3.915 / 3.893 / 3.894.
+#ifndef WMAR_ATT_LATE_KV
+#define WMAR_ATT_LATE_KV 2
+#endif
 #ifndef WMAR_ATT_PLAIN_KV
 #define WMAR_KV_LD(P) ld_nt(P)
 #else
@@ -1693,21 +1752,24 @@ struct AttnArgs {
 // CH 1-KiB loads (CH*RPI rows); wave w takes chunks w, w+NWA, ...  and keeps a running
 // (max, sum, weighted V sum) in registers -- K and V of a chunk are requested together, the next
 // chunk is in flight while the current one is reduced.  The NWA partial results meet in LDS.
-template <int HD, int NWA, bool PF2 = false>
+// MODE (AttnArgs::mode) and RM (AttnArgs::rowmajor) are template parameters (round 5): as run-time branches around the prologue's
+// loads they left merge points behind which hipcc's s_waitcnt pass waited for EVERY outstanding load (vmcnt(0)) -- the cache chunks
+// requested in front of the q / k / v algebra had to land before it could even begin.
+template <int HD, int NWA, bool PF2 = false, int MODE = 0, bool RM = false>
 __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
     // LPRA lanes (one float4 each) cover a cache row; rows are laid on LPR = next power of two lanes so
     // that the row reductions are xor-shuffles (hd = 80: 20 of 32 lanes active, 2 rows per load).
     constexpr int LPRA = HD / 4;
     constexpr int LPR = LPRA <= 8 ? 8 : (LPRA <= 16 ? 16 : 32);
     constexpr int RPI = 64 / LPR;
-    constexpr int CH = 8;
+    constexpr int CH = WMAR_ATT_CH;
     constexpr int ROWS = CH * RPI;
     static_assert(HD % 4 == 0 && LPRA <= 32, "head_dim must be a multiple of 4, at most 128");
     __shared__ __attribute__((aligned(16))) float part[NWA][HD + 4];    // per wave: weighted V sum [HD], max, sum (16-B rows)
     __shared__ __attribute__((aligned(16))) float qkv_s[3][HD];
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = NWA == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int T = *a.pos_dev + 1;
     const int subr = lane % LPR, rsel = lane / LPR;
     const bool lane_on = subr < LPRA;            // idle lanes of a padded row read lane 0's data and are masked
@@ -1729,6 +1791,7 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
     }
     float4 kA[CH], vA[CH], kB[CH], vB[CH];
     float4 q, knew, vnew;
+    WMAR_ST_BEGIN
 #ifdef WMAR_ATT_TRACE
     unsigned long long tr[5];
     tr[0] = __builtin_amdgcn_s_memtime();
@@ -1760,7 +1823,7 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
     for (int which = 0; which < 3; ++which) {
         const int n = which * a.D + h * HD + sub * 4;          // first of this lane's 4 columns
         // packed operand layout, or row-major pieces [rows][3 D] (k_qkvx_bx, round 5): this lane's float4 of row b
-        const long long idx = a.rowmajor ? ((long long)b * (3 * a.D) + n) >> 2
+        const long long idx = RM ? ((long long)b * (3 * a.D) + n) >> 2
                                          : ((long long)(n >> 3) * a.MT + mt) * 64 + (b & 31) + 32 * ((n >> 2) & 1);
         if (w == 0) {           // wave-uniform
 #pragma unroll
@@ -1768,15 +1831,35 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
                 const int pc = min(rsel + pi * RPI, a.S - 1);
                 sl[which][pi] = a.qkv_slabs[(long long)pc * a.slab_stride + idx];
             }
-            cc[which] = *(const float4*)((a.mode == 0 ? a.c1 : a.bias) + n);     // (mode 1 has no c1: any valid address, value unused)
+            cc[which] = *(const float4*)((MODE == 0 ? a.c1 : a.bias) + n);     // (mode 1 has no c1: any valid address, value unused)
             bb[which] = *(const float4*)(a.bias + n);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    // LATE (round 5, one wave per (sequence, head)): the cache chunks are requested only once the prologue's operands are HERE.
+    // In-loop stamps (profiles/r05_stamp_table_*): with the first chunk requested up front, the six waves of a CU queued 96 KiB of K/V
+    // in front of each other's 5 KiB of prologue operands -- they landed 4.2 us after entry on average, 12.3 at worst, and the
+    // late waves were the launch's stragglers (last workgroup out 4.2 us after the mean).  Now every wave gets its operands at
+    // L2 latency, requests TWO chunks, and finishes q / k / v while they fly.
+    constexpr bool LATE = WMAR_ATT_LATE_KV && NWA == 1;
+    constexpr bool LATE2 = LATE && WMAR_ATT_LATE_KV == 1;      // both chunks in front of the q / k / v algebra (2: the second one behind it)
+    if (LATE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef WMAR_STAMPS
+        st_[2] = __builtin_amdgcn_s_memtime();
+#endif
+    }
     WMAR_ATT_LOAD(kA, vA, w)                    // unconditional (clamped rows): see the refills below
-    if (PF2) { WMAR_ATT_LOAD(kB, vB, w + NWA) }
+    if (PF2 || LATE2) { WMAR_ATT_LOAD(kB, vB, w + NWA) }
     __builtin_amdgcn_sched_barrier(0);
     if (w == 0) {
+#ifdef WMAR_STAMPS
+        if (!LATE) {
+            // (the prologue's operands only: the cache chunk behind them stays in flight -- 16 K/V loads were issued after them)
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            st_[2] = __builtin_amdgcn_s_memtime();
+        }
+#endif
 #ifdef WMAR_ATT_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tr[1] = __builtin_amdgcn_s_memtime();
@@ -1812,7 +1895,7 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
 #pragma unroll
             for (int which = 0; which < 3; ++which) {
                 const float4 acc = accs[which];
-                if (a.mode == 0) {
+                if (MODE == 0) {
                     r[which] = make_float4(rstd * (acc.x - mu * cc[which].x) + bb[which].x,
                                            rstd * (acc.y - mu * cc[which].y) + bb[which].y,
                                            rstd * (acc.z - mu * cc[which].z) + bb[which].z,
@@ -1821,7 +1904,7 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
                     r[which] = make_float4(acc.x + bb[which].x, acc.y + bb[which].y, acc.z + bb[which].z, acc.w + bb[which].w);
                 }
             }
-            if (a.mode == 1) {
+            if (MODE == 1) {
                 // q_norm / k_norm: LayerNorm over the hd values of this head (eps 1e-6, affine)
 #pragma unroll
                 for (int which = 0; which < 2; ++which) {
@@ -1850,7 +1933,11 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
             }
         }
     }
-    __syncthreads();
+    // One wave per workgroup: the hand-over of q / k / v through LDS needs no s_barrier -- and hipcc's __syncthreads() drains EVERY
+    // outstanding load first (s_waitcnt vmcnt(0)): the cache chunks requested above would have to land before the streaming loop may
+    // even start (stamps: "finish q/k/v" 6.6 us with two chunks in flight).  LDS operations of one wave execute in order.
+    if (NWA > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    WMAR_ST(6)
 #ifdef WMAR_ATT_TRACE
     tr[2] = __builtin_amdgcn_s_memtime();
 #endif
@@ -1888,7 +1975,7 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
     // The refills inside the loop are UNCONDITIONAL (rows past the cache clamp to row T-1: L1 hits): a load under a run-time branch
     // makes hipcc's s_waitcnt pass take the smaller outstanding count of the two paths at the merge, i.e. every use of chunk c
     // then waits for chunk c+1's loads as well and the double buffer degenerates to one chunk in flight.
-    if (!PF2) { WMAR_ATT_LOAD(kB, vB, w + NWA) }
+    if (!PF2 && !LATE2) { WMAR_ATT_LOAD(kB, vB, w + NWA) }
     __builtin_amdgcn_sched_barrier(0);
     for (int c = w; c < nchunk; c += 2 * NWA) {
         WMAR_ATT_CHUNK(kA, vA, c)
@@ -1902,6 +1989,7 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
     }
 #undef WMAR_ATT_LOAD
 #undef WMAR_ATT_CHUNK
+    WMAR_ST(3)
 #ifdef WMAR_ATT_TRACE
     tr[3] = __builtin_amdgcn_s_memtime();
 #endif
@@ -1916,7 +2004,7 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
         *(float4*)(&part[w][sub * 4]) = acc;
         if (sub == 0) { part[w][HD] = m; part[w][HD + 1] = l; }
     }
-    __syncthreads();
+    if (NWA > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
     if (w == 0 && rsel == 0 && lane_on) {
         float M = part[0][HD];
 #pragma unroll
@@ -1939,6 +2027,7 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
         if (a.yq) bx_store_planes4(a.yq, a.MT, kb, hf, mt, b & 31, yv);
         else a.y[((long long)kb * a.MT + mt) * 64 + (b & 31) + 32 * hf] = yv;
     }
+    WMAR_ST_END(a.trace, blockIdx.x)
 #ifdef WMAR_ATT_TRACE
     if (a.trace && threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -95,6 +95,10 @@ struct wmar_gpt {
     int inject_fail = 0;           // WMAR_INJECT_SYNC_FAIL=1 at creation (tests): the next fused call finds the timeout flag raised
     int fallbacks = 0;             // calls re-run on the two-launch path after a failed in-launch barrier (wmar_gpt_plan_info reports it)
     unsigned long long* dbg_sums = nullptr; int dbg_slot = 0;   // dev only: see k_dbg_sum
+    unsigned long long* stamps = nullptr;   // dev only (-DWMAR_STAMPS, WMAR_STAMPS=1 at creation): [L][5 roles][WMAR_STAMP_UNITS][8] timeline stamps
+    unsigned long long* stamp_slot(int l, int role) const {
+        return stamps ? stamps + ((long long)(l * 5 + role) * WMAR_STAMP_UNITS) * 8 : nullptr;
+    }
     bool no_bx = false;           // dev knob WMAR_NO_BX: keep the fp32-MFMA k_qkvx
     int force_s[3] = {0, 0, 0};   // tuning knobs: WMAR_S_QKV / WMAR_S_PROJ / WMAR_S_FC2
     double step_ms = 0.0;
@@ -283,6 +287,7 @@ struct StepPlan {
         q.stats = g->stats_q; q.out = g->qkv_slabs; q.out_stride = 3 * act;
         q.KB = KBD; q.NT = 3 * D / 32; q.S = S_qx;
         q.cap = ((q.NT / 4) * q.S + 7) / 8;
+        q.trace = g->stamp_slot(l, 0);
         g->span_begin(WMAR_T_QKV, st);
         int rc;
         if (qkv_bx()) { q.Wp = w.wqkvx_bx; rc = launch_qkvx_bx(q, S_in, st); }   // 33..64 rows: bf16 matrix pipe
@@ -313,6 +318,7 @@ struct StepPlan {
         t.rowmajor = qkv_bx() ? 1 : 0;      // k_qkvx_bx writes its pieces row-major (decoder_kernels.h)
         t.kcache = g->kcache + l * lstride; t.vcache = g->vcache + l * lstride; t.y = g->y; t.yq = proj_bx ? g->yq : nullptr; t.pos_dev = g->pos_dev;
         t.D = D; t.H = g->H; t.Tmax = g->Tmax; t.MT = MT; t.scale = 1.0f / sqrtf((float)g->hd);
+        t.trace = g->stamp_slot(l, 1);
         int nwa = g->att_nw;   // chosen per phase by the caller (generate / profile_role)
 #ifdef WMAR_DEV_KNOBS
         { const char* e = getenv("WMAR_ATT_DBG"); t.dbg = e ? atoi(e) : 0; }
@@ -320,10 +326,11 @@ struct StepPlan {
 #endif
         const dim3 grid((unsigned)(B * g->H));
         g->span_begin(WMAR_T_ATTN, st);
-#define WMAR_ATT_LAUNCH2(HDV, PF)                                                                         \
-        if (nwa == 1) hipLaunchKernelGGL((k_attn_decode<HDV, 1, PF>), grid, dim3(64), 0, st, t);               \
-        else if (nwa == 2) hipLaunchKernelGGL((k_attn_decode<HDV, 2, PF>), grid, dim3(128), 0, st, t);         \
-        else hipLaunchKernelGGL((k_attn_decode<HDV, 4, PF>), grid, dim3(256), 0, st, t);
+#define WMAR_ATT_LAUNCH3(HDV, PF, RMV)                                                                    \
+        if (nwa == 1) hipLaunchKernelGGL((k_attn_decode<HDV, 1, PF, 0, RMV>), grid, dim3(64), 0, st, t);       \
+        else if (nwa == 2) hipLaunchKernelGGL((k_attn_decode<HDV, 2, PF, 0, RMV>), grid, dim3(128), 0, st, t); \
+        else hipLaunchKernelGGL((k_attn_decode<HDV, 4, PF, 0, RMV>), grid, dim3(256), 0, st, t);
+#define WMAR_ATT_LAUNCH2(HDV, PF) if (t.rowmajor) { WMAR_ATT_LAUNCH3(HDV, PF, true) } else { WMAR_ATT_LAUNCH3(HDV, PF, false) }
 #define WMAR_ATT_LAUNCH(HDV) if (pf2) { WMAR_ATT_LAUNCH2(HDV, true) } else { WMAR_ATT_LAUNCH2(HDV, false) }
 #ifdef WMAR_ATT_PF2
         const bool pf2 = true;
@@ -333,6 +340,7 @@ struct StepPlan {
         if (g->hd == 64) { WMAR_ATT_LAUNCH(64) }
         else if (g->hd == 32) { WMAR_ATT_LAUNCH(32) }
         else { WMAR_ATT_LAUNCH(128) }
+#undef WMAR_ATT_LAUNCH3
 #undef WMAR_ATT_LAUNCH2
 #undef WMAR_ATT_LAUNCH
         g->span_end(st);
@@ -346,6 +354,7 @@ struct StepPlan {
             x.Wq = g->layers[l].wproj_bx; x.Xq = g->yq; x.out = g->slabs; x.slab_stride = act; x.KU = D / 16; x.S = 4;
             q.x = xcur; q.bias = g->layers[l].bproj; q.stats = g->stats; q.sync = g->xsync; q.fail = g->xsync + 8 * 64;
             q.tiles_per_group = D / 32 / 8;
+            q.trace = g->stamp_slot(l, 2);
             g->span_begin(WMAR_T_PROJ, st);
             const int rc = launch_bx_xr<BX_PER, 4>(q, D, st);
             g->span_end(st);
@@ -380,6 +389,7 @@ struct StepPlan {
             Fc1xArgs x{};
             x.W16 = w.wfc1x16; x.W8 = w.wfc1x8; x.Xp = xcur; x.bias = w.bfc1; x.c1 = w.cfc1; x.stats = g->stats; x.n_chunks = nch_ln2; x.K = D;
             x.out = g->hbuf; x.KU = D / 16;
+            x.trace = g->stamp_slot(l, 3);
             hipLaunchKernelGGL(k_fc1x, dim3((unsigned)(4 * D / 24)), dim3(256), 0, st, x);
             rc = launch_status("k_fc1x");
         } else {
@@ -392,6 +402,7 @@ struct StepPlan {
         GemmArgs q = base();
         q.Wp = g->layers[l].wfc2; q.Xp = g->hbuf; q.KB = KBF; q.NT = D / 32;
         q.out_packed = g->slabs; q.slab_stride = act; q.n_hi = fc2_hi;
+        q.trace = g->stamp_slot(l, 4);
         int S = 1;
         g->span_begin(WMAR_T_FC2, st);
         int rc = gemm_split(q, &S, st, S_fc2);
@@ -501,6 +512,12 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
     // WMAR_NO_BX=1 at engine creation (any build): QKV and the output projection stay on the fp32-input MFMA (k_qkvx / k_gemm).  The
     // bf16-piece split turns an infinite operand into NaN where fp32 arithmetic gives +-inf (bx_split.h).
     g->no_bx = getenv("WMAR_NO_BX") != nullptr;
+#ifdef WMAR_STAMPS
+    if (getenv("WMAR_STAMPS")) {
+        const size_t n = (size_t)L * 5 * WMAR_STAMP_UNITS * 8;
+        if (hipMalloc(&g->stamps, n * 8) != hipSuccess || hipMemset(g->stamps, 0, n * 8) != hipSuccess) g->stamps = nullptr;
+    }
+#endif
 #ifdef WMAR_DEV_KNOBS
     if (getenv("WMAR_DBG_SUMS")) { if (hipMalloc(&g->dbg_sums, 4096 * 8) != hipSuccess) g->dbg_sums = nullptr; }
     g->no_bx_qkv = getenv("WMAR_NO_BX_QKV") != nullptr; g->no_bx_proj = getenv("WMAR_NO_BX_PROJ") != nullptr;   // one role at a time (bisecting)
@@ -795,6 +812,17 @@ int wmar_gpt_plan_info(wmar_gpt* g, int64_t B, char* buf, int64_t buf_len) {
     WMAR_REQUIRE(n > 0 && n < buf_len, "plan_info: buffer of %lld bytes too small", (long long)buf_len);
     return WMAR_OK;
 }
+
+#ifdef WMAR_STAMPS
+// dev only: the timeline stamps of the LAST decode step that ran, [L][5][WMAR_STAMP_UNITS][8] u64 copied to the host
+int wmar_gpt_debug_stamps(wmar_gpt* g, unsigned long long* out, long long n_u64) {
+    WMAR_REQUIRE(g && g->stamps && out, "debug_stamps: not enabled (WMAR_STAMPS=1 at creation of a -DWMAR_STAMPS build)");
+    const long long n = (long long)g->L * 5 * WMAR_STAMP_UNITS * 8;
+    WMAR_HIP_CHECK(hipDeviceSynchronize());
+    WMAR_HIP_CHECK(hipMemcpy(out, g->stamps, (size_t)(n_u64 < n ? n_u64 : n) * 8, hipMemcpyDeviceToHost));
+    return WMAR_OK;
+}
+#endif
 
 #ifdef WMAR_DEV_KNOBS
 // dev only: the checksums of the last decode step (k_dbg_sum), n_out slots copied to the host

@@ -564,9 +564,9 @@ struct RarPlan {
         { const char* e = getenv("WMAR_RAR_ATT_NW"); if (e) nwa = atoi(e); }
 #endif
 #define WMAR_RAR_ATT(HDV)                                                                                   \
-        if (nwa == 1) hipLaunchKernelGGL((k_attn_decode<HDV, 1>), grid, dim3(64), 0, st, t);                \
-        else if (nwa == 4) hipLaunchKernelGGL((k_attn_decode<HDV, 4>), grid, dim3(256), 0, st, t);          \
-        else hipLaunchKernelGGL((k_attn_decode<HDV, 2>), grid, dim3(128), 0, st, t);
+        if (nwa == 1) hipLaunchKernelGGL((k_attn_decode<HDV, 1, false, 1, false>), grid, dim3(64), 0, st, t);                \
+        else if (nwa == 4) hipLaunchKernelGGL((k_attn_decode<HDV, 4, false, 1, false>), grid, dim3(256), 0, st, t);          \
+        else hipLaunchKernelGGL((k_attn_decode<HDV, 2, false, 1, false>), grid, dim3(128), 0, st, t);
         switch (g->hd) {
             case 32: WMAR_RAR_ATT(32) break;
             case 48: WMAR_RAR_ATT(48) break;
