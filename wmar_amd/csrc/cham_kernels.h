@@ -487,11 +487,14 @@ static __global__ void k_rope_table(float2* tab, int T, int half, float theta) {
     tab[idx] = make_float2(cs, sn);
 }
 
+#ifndef WMAR_CHAM_ATT_CH
+#define WMAR_CHAM_ATT_CH 4      // 1-KiB loads of K (and of V) per chunk of k_cham_attn (bf16 rows: 16 cached rows of head_dim 128 at 4)
+#endif
 template <int HD, int NWA>
 __global__ __launch_bounds__(NWA * 64) void k_cham_attn(ChamAttnArgs a) {
     constexpr int LPR = HD / 8;            // lanes per cached row (8 bf16 each)
     constexpr int RPI = 64 / LPR;          // rows per wave-wide load
-    constexpr int CH = 4;
+    constexpr int CH = WMAR_CHAM_ATT_CH;
     constexpr int ROWS = CH * RPI;
     __shared__ __attribute__((aligned(16))) float part[NWA][HD + 4];
     __shared__ __attribute__((aligned(16))) float qkv_s[3][HD];

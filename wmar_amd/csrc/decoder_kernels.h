@@ -1709,6 +1709,10 @@ static int launch_bx_xr(const BxrArgs& q, int N, hipStream_t st) {
 #ifndef WMAR_ATT_CH
 #define WMAR_ATT_CH 2
 #endif
+#ifndef WMAR_A80_NU
+#define WMAR_A80_NU 2           // k_attn_decode80: 1-KiB main loads of K (and of V) per chunk, 4 cached rows each (round 5: 2 instead of
+                                // 4 -- RAR-XL 4.04 -> 3.98 ms per step, same box; 1: 3.97)
+#endif
 // Order of the first requests of a one-wave workgroup (LATE in k_attn_decode): 0 = first chunk requested together with the prologue's
 // operands (round 4), 1 = both chunks once the operands are here, 2 = first chunk once they are here, the second behind the q / k / v
 // algebra.  At CH 2 the three are within noise (3.798 / 3.814 / 3.798); at CH 8: 3.915 / 3.893 / 3.894.
@@ -2047,14 +2051,16 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode(AttnArgs a) {
 // so it picks the main partial score out of its own registers (3 selects, no cross-lane traffic), and a main lane fetches the tail
 // partial of row (u, g) from lane 16 g + 4 u of its own 16-lane row (one __shfl per main load).  The prologue (QKV pieces, bias,
 // q / k LayerNorm over the 80 values, cache append) is k_attn_decode's.
-template <int NWA>
+template <int NWA, int MODE = 1>     // MODE: AttnArgs::mode at compile time (see k_attn_decode); RAR is the only head_dim-80 user
 __global__ __launch_bounds__(NWA * 64) void k_attn_decode80(AttnArgs a) {
-    constexpr int HD = 80, LPRA = 20, LPR = 32, RPI = 2, ROWS = 16;
+    // NU main loads per chunk (4 rows each): chunks of 4 NU rows.  The tail load always spans 16 rows' worth of lanes; with NU < 4 the
+    // lane quads of the rows past the chunk re-read a clamped row and contribute nothing (their weight is 0).
+    constexpr int HD = 80, LPRA = 20, LPR = 32, RPI = 2, NU = WMAR_A80_NU, ROWS = 4 * NU;
     __shared__ __attribute__((aligned(16))) float part[NWA][HD + 4];
     __shared__ __attribute__((aligned(16))) float qkv_s[3][HD];
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = NWA == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int T = *a.pos_dev + 1;
     // prologue roles (k_attn_decode's layout: 32 lanes per row, 20 active)
     const int subr = lane % LPR, rsel = lane / LPR;
@@ -2072,15 +2078,15 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode80(AttnArgs a) {
     const float* Vtail = Vc + 64 + t4 * 4;
     // rows past T-1 are clamped to T-1 and replaced from registers / masked below
 #define WMAR_A80_LOAD(KM, KT, VM, VT, C0)                                                \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                      \
+    _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                     \
         const int t = min((C0) * ROWS + 4 * u + g16, T - 1);                             \
         KM[u] = WMAR_KV_LD((const float4*)(Kmain + (long long)t * HD));                  \
         VM[u] = WMAR_KV_LD((const float4*)(Vmain + (long long)t * HD));                  \
     }                                                                                    \
-    { const int t = min((C0) * ROWS + 4 * ut + g16, T - 1);                              \
+    { const int t = min((C0) * ROWS + 4 * min(ut, NU - 1) + g16, T - 1);                 \
       KT = WMAR_KV_LD((const float4*)(Ktail + (long long)t * HD));                       \
       VT = WMAR_KV_LD((const float4*)(Vtail + (long long)t * HD)); }
-    float4 kmA[4], vmA[4], ktA, vtA, kmB[4], vmB[4], ktB, vtB;
+    float4 kmA[NU], vmA[NU], ktA, vtA, kmB[NU], vmB[NU], ktB, vtB;
     // PF2: the wave's first TWO chunks are requested before the prologue (32 KiB in flight per wave: with 1 / 2 / 4 waves the
     // whole cache up to 64 / 128 / 256 rows streams while q/k/v are finished); otherwise one, the second from inside the loop.
     // (Measured dead end: clamping the first chunk to the cache's capacity instead of its fill, so that its loads need not wait
@@ -2116,7 +2122,7 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode80(AttnArgs a) {
                 const int pc = min(rsel + pi * RPI, a.S - 1);
                 sl[which][pi] = a.qkv_slabs[(long long)pc * a.slab_stride + idx];
             }
-            cc[which] = *(const float4*)((a.mode == 0 ? a.c1 : a.bias) + n);     // (mode 1 has no c1: any valid address, value unused)
+            cc[which] = *(const float4*)((MODE == 0 ? a.c1 : a.bias) + n);     // (mode 1 has no c1: any valid address, value unused)
             bb[which] = *(const float4*)(a.bias + n);
         }
     }
@@ -2155,7 +2161,7 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode80(AttnArgs a) {
 #pragma unroll
             for (int which = 0; which < 3; ++which) {
                 const float4 acc = accs[which];
-                if (a.mode == 0) {
+                if (MODE == 0) {
                     r[which] = make_float4(rstd * (acc.x - mu * cc[which].x) + bb[which].x,
                                            rstd * (acc.y - mu * cc[which].y) + bb[which].y,
                                            rstd * (acc.z - mu * cc[which].z) + bb[which].z,
@@ -2164,7 +2170,7 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode80(AttnArgs a) {
                     r[which] = make_float4(acc.x + bb[which].x, acc.y + bb[which].y, acc.z + bb[which].z, acc.w + bb[which].w);
                 }
             }
-            if (a.mode == 1) {
+            if (MODE == 1) {
                 // q_norm / k_norm: LayerNorm over the hd values of this head (eps 1e-6, affine)
 #pragma unroll
                 for (int which = 0; which < 2; ++which) {
@@ -2193,7 +2199,7 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode80(AttnArgs a) {
             }
         }
     }
-    __syncthreads();
+    if (NWA > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();     // one wave: no s_barrier, no vmcnt(0) drain (k_attn_decode)
     const float4 qM = *(const float4*)(&qkv_s[0][m16 * 4]), qT = *(const float4*)(&qkv_s[0][64 + t4 * 4]);
     const float4 knM = *(const float4*)(&qkv_s[1][m16 * 4]), knT = *(const float4*)(&qkv_s[1][64 + t4 * 4]);
     const float4 vnM = *(const float4*)(&qkv_s[2][m16 * 4]), vnT = *(const float4*)(&qkv_s[2][64 + t4 * 4]);
@@ -2203,13 +2209,13 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode80(AttnArgs a) {
     float4 accM = make_float4(0.f, 0.f, 0.f, 0.f), accT = accM;
 #define WMAR_A80_CHUNK(KM, KT, VM, VT, C0)                                               \
     {                                                                                    \
-        const int tt = (C0) * ROWS + 4 * ut + g16;                                       \
+        const int tt = (C0) * ROWS + 4 * min(ut, NU - 1) + g16;                          \
         if (tt >= T - 1) { KT = knT; VT = vnT; }                                         \
         float pt = KT.x * qT.x + KT.y * qT.y + KT.z * qT.z + KT.w * qT.w;                \
         pt += __shfl_xor(pt, 1); pt += __shfl_xor(pt, 2);     /* the row's 16 tail floats */ \
-        float sc[4];                                                                     \
+        float sc[NU];                                                                    \
         float cm = -INFINITY;                                                            \
-        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                  \
+        _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                 \
             const int t = (C0) * ROWS + 4 * u + g16;                                     \
             if (t >= T - 1) { KM[u] = knM; VM[u] = vnM; }                                \
             float p = KM[u].x * qM.x + KM[u].y * qM.y + KM[u].z * qM.z + KM[u].w * qM.w; \
@@ -2224,8 +2230,8 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode80(AttnArgs a) {
         const float rs = __expf(m - mn);       /* 0 on the first chunk (m = -inf) */     \
         l *= rs; accM.x *= rs; accM.y *= rs; accM.z *= rs; accM.w *= rs;                 \
         accT.x *= rs; accT.y *= rs; accT.z *= rs; accT.w *= rs;                          \
-        float e4[4];                                                                     \
-        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                  \
+        float e4[4] = {0.f, 0.f, 0.f, 0.f};                                              \
+        _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                 \
             const float e = __expf(sc[u] - mn);                                          \
             e4[u] = e;                                                                   \
             l += e;                                                                      \
@@ -2264,7 +2270,7 @@ __global__ __launch_bounds__(NWA * 64) void k_attn_decode80(AttnArgs a) {
     if (lane < 16) *(float4*)(&part[w][lane * 4]) = accM;
     if (lane < 4) *(float4*)(&part[w][64 + lane * 4]) = accT;
     if (lane == 0) { part[w][HD] = m; part[w][HD + 1] = l; }
-    __syncthreads();
+    if (NWA > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();     // one wave: no s_barrier, no vmcnt(0) drain (k_attn_decode)
     if (w == 0 && lane < LPRA) {
         float M = part[0][HD];
 #pragma unroll
