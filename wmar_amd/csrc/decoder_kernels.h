@@ -804,6 +804,7 @@ struct QkvxArgs {
     float4* out;               // [S][3D/8][MT][64] split-K pieces of the projection
     long long out_stride;      // float4 units
     int KB, NT, S, cap;        // cap: workgroup slots per XCD (grid = 8 * cap)
+    int nkeep;                 // k_qkvx_bx: column groups per K slice that share the keeper duty (statistics chunks = S * nkeep)
     unsigned long long* trace; // dev only (WMAR_QX_TRACE): 4 timestamps per wave
     unsigned long long* trace_chunks;   // dev only: start of each chunk relative to the first, per wave
 };
@@ -1128,7 +1129,10 @@ __global__ __launch_bounds__(512) void k_qkvx_bx(QkvxArgs a) {
     const int kb0 = 2 * (int)((unsigned)s * (unsigned)KU / (unsigned)a.S);
     const int kb1 = 2 * (int)((unsigned)(s + 1) * (unsigned)KU / (unsigned)a.S);
     const int nkb = kb1 - kb0, nch = (nkb + QX_CK - 1) / QX_CK;
-    const bool keeper = g == 0;
+    // Keeper duty -- publishing x' and the fp64 row sums of the K slice -- is shared by the first `nkeep` column groups of a slice
+    // (round 5; chunk c belongs to group c % nkeep): with ONE keeper per slice its stagers' extra stores and fp64 sums made those 7
+    // workgroups the launch's stragglers (in-loop stamps: last workgroup out 2.2 us after the mean).  Statistics chunk = s * nkeep + g.
+    const bool keeper = g < a.nkeep;
 
     if (w >= 4) {
         // ------------------------------------------------------------------------------------------ staging waves
@@ -1153,7 +1157,7 @@ __global__ __launch_bounds__(512) void k_qkvx_bx(QkvxArgs a) {
         }                                                                                               \
     }
 // wave sw stages k-block sw of the chunk: step sw / 2, operand lanes m + 32 (sw % 2), this lane's 8 bytes = half
-#define WMAR_QX_FINISH(XV, BB, SL, SKB, BUF)                                                           \
+#define WMAR_QX_FINISH(XV, BB, SL, SKB, BUF, CIDX)                                                     \
     if (SKB < kb1) {                                                                                    \
         const bool short_tile = a.n_hi > 0 && (SKB >> 2) >= a.n_hi;                                     \
         _Pragma("unroll") for (int i = 0; i < MTW; ++i) {                                               \
@@ -1171,7 +1175,7 @@ __global__ __launch_bounds__(512) void k_qkvx_bx(QkvxArgs a) {
             bx_split2(r.z, r.w, h1, m1, l1);                                                            \
             u32x2* d = (u32x2*)&xq[BUF][sw >> 1][i][0][(lane & 31) + 32 * (sw & 1)] + half;             \
             d[0] = u32x2{h0, h1}; d[128] = u32x2{m0, m1}; d[256] = u32x2{l0, l1};                       \
-            if (keeper) {                                                                               \
+            if (keeper && (CIDX) % a.nkeep == g) {                                                      \
                 a.x_out[((long long)SKB * MTW + i) * 64 + lane] = r;                                    \
                 sum[i] += (double)r.x + (double)r.y + (double)r.z + (double)r.w;                        \
                 sq[i] += WMAR_QX_SQ4(r);        /* never a v_fmac_f64 chain: common.h */                \
@@ -1181,19 +1185,19 @@ __global__ __launch_bounds__(512) void k_qkvx_bx(QkvxArgs a) {
         WMAR_QX_ISSUE(xvA, bbA, slA, skbA, 0)
         WMAR_QX_ISSUE(xvB, bbB, slB, skbB, 1)
         __builtin_amdgcn_sched_barrier(0);
-        WMAR_QX_FINISH(xvA, bbA, slA, skbA, 0)
+        WMAR_QX_FINISH(xvA, bbA, slA, skbA, 0, 0)
         __builtin_amdgcn_sched_barrier(0);
         WMAR_QX_ISSUE(xvA, bbA, slA, skbA, 2)
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                   // barrier(-1): chunk 0 is in LDS
         for (int c = 0; c + 1 < nch; c += 2) {
-            WMAR_QX_FINISH(xvB, bbB, slB, skbB, 1)         // chunk c+1
+            WMAR_QX_FINISH(xvB, bbB, slB, skbB, 1, c + 1)  // chunk c+1
             __builtin_amdgcn_sched_barrier(0);
             WMAR_QX_ISSUE(xvB, bbB, slB, skbB, c + 3)
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();                               // barrier(c)
             if (c + 2 >= nch) break;
-            WMAR_QX_FINISH(xvA, bbA, slA, skbA, 0)         // chunk c+2
+            WMAR_QX_FINISH(xvA, bbA, slA, skbA, 0, c + 2)  // chunk c+2
             __builtin_amdgcn_sched_barrier(0);
             WMAR_QX_ISSUE(xvA, bbA, slA, skbA, c + 4)
             __builtin_amdgcn_sched_barrier(0);
@@ -1224,7 +1228,7 @@ __global__ __launch_bounds__(512) void k_qkvx_bx(QkvxArgs a) {
 #else
                 for (int ww = 0; ww < 4; ++ww) { ts += red[ww][i][r][0] + red[ww][i][r + 32][0]; tss += red[ww][i][r][1] + red[ww][i][r + 32][1]; }
 #endif
-                double* o = a.stats + ((long long)s * (MTW * 32) + i * 32 + r) * 2;
+                double* o = a.stats + ((long long)(s * a.nkeep + g) * (MTW * 32) + i * 32 + r) * 2;
                 o[0] = ts; o[1] = tss;
             }
         }

@@ -246,6 +246,7 @@ struct StepPlan {
     // the predicates the launches below use (wmar_gpt_plan_info reports from the same ones)
     bool qkv_bx() const { return S_qx > 0 && MT == 2 && g->layers[0].wqkvx_bx && !g->no_bx && !g->no_bx_qkv; }
     bool fc1_x() const { return MT == 2 && g->layers[0].wfc1x16; }
+    int qx_nkeep() const { const int G = 3 * D / 128; return G >= 4 && S_qx * 4 <= STAT_CHUNKS_MAX ? 4 : 1; }   // keeper groups per K slice (k_qkvx_bx)
     static bool head_narrow() { static int v = -1; if (v < 0) v = getenv("WMAR_HEAD_NARROW") ? 1 : 0; return v != 0; }   // A/B: the two-launch 32-column head
     int split_for(int NT, int KB) const { return pick_split(MT % 2 == 0 ? NT * (MT / 2) : NT * MT, KB, 4); }
     GemmArgs base() const {
@@ -287,6 +288,7 @@ struct StepPlan {
         q.stats = g->stats_q; q.out = g->qkv_slabs; q.out_stride = 3 * act;
         q.KB = KBD; q.NT = 3 * D / 32; q.S = S_qx;
         q.cap = ((q.NT / 4) * q.S + 7) / 8;
+        q.nkeep = qx_nkeep();
         q.trace = g->stamp_slot(l, 0);
         g->span_begin(WMAR_T_QKV, st);
         int rc;
@@ -312,7 +314,7 @@ struct StepPlan {
         const long long lstride = (long long)g->Bmax * g->H * g->Tmax * g->hd;
         AttnArgs t{};
         t.qkv_slabs = g->qkv_slabs; t.slab_stride = 3 * act; t.K = D; t.invK = 1.0 / (double)D;
-        if (S_qx > 0) { t.S = S_qx; t.stats = g->stats_q; t.n_chunks = S_qx; }
+        if (S_qx > 0) { t.S = S_qx; t.stats = g->stats_q; t.n_chunks = qkv_bx() ? S_qx * qx_nkeep() : S_qx; }
         else { t.S = S_qkv; t.stats = g->stats; t.n_chunks = nch; }
         t.c1 = w.cqkv; t.bias = w.bqkv;
         t.rowmajor = qkv_bx() ? 1 : 0;      // k_qkvx_bx writes its pieces row-major (decoder_kernels.h)
@@ -619,7 +621,7 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
     if (g->MTmax >= 2 && D % BX_KSLICE == 0) TRY(g->alloc(&g->yq, (size_t)D / 16 * 2 * 3 * 64));
     TRY(g->alloc(&g->qbuf, Mpad * D));
     TRY(g->alloc(&g->stats, (size_t)STAT_CHUNKS_MAX * Mpad * 2));
-    TRY(g->alloc(&g->stats_q, (size_t)QKV_SLABS_MAX * Mpad * 2));
+    TRY(g->alloc(&g->stats_q, (size_t)QKV_SLABS_MAX * 4 * Mpad * 2));      // x 4: k_qkvx_bx's keeper groups per K slice
     const size_t kv = (size_t)L * g->Bmax * H * g->Tmax * hd;
     TRY(g->alloc(&g->kcache, kv));
     TRY(g->alloc(&g->vcache, kv));
