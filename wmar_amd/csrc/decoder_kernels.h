@@ -696,6 +696,12 @@ static __global__ __launch_bounds__(256) void k_fc1x(Fc1xArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     float mu, rstd;       // LayerNorm statistics of row = lane, fetched behind the first operands
     ln_row_stats(a.stats, a.n_chunks, 64, lane, a.K, &mu, &rstd);
+    // the epilogue's column constants (folded-LN row sums, bias) of this wave's output groups gi = w and gi = w + 4 (waves 0, 1):
+    // requested here (round 5) -- inside the epilogue they were a dependent L2 round trip per group with every store behind it
+    // (in-loop stamps: 2.5 us from the last MFMA to the last store acknowledged)
+    const int nA_ = tile * 24 + 4 * (lane >> 4), nB_ = tile * 24 + 16 + 4 * (w & 1);
+    const float4 ccA_ = *(const float4*)(a.c1 + nA_), bbA_ = *(const float4*)(a.bias + nA_);
+    const float4 ccB_ = *(const float4*)(a.c1 + nB_), bbB_ = *(const float4*)(a.bias + nB_);
     __builtin_amdgcn_sched_barrier(0);
     WMAR_ST_LANDED(2)
 #ifdef WMAR_FX_TRACE
@@ -755,8 +761,8 @@ static __global__ __launch_bounds__(256) void k_fc1x(Fc1xArgs a) {
         const int m = gi < 4 ? 16 * gi + (lane & 15) : lane;
         const int n = tile * 24 + (gi < 4 ? 4 * (lane >> 4) : 16 + 4 * (gi - 4));
         const float mm = __shfl(mu, m), rs = __shfl(rstd, m);
-        const float4 cc = *(const float4*)(a.c1 + n);
-        const float4 bb = *(const float4*)(a.bias + n);
+        const float4 cc = gi < 4 ? ccA_ : ccB_;
+        const float4 bb = gi < 4 ? bbA_ : bbB_;
         o[0] = gelu_erf(rs * (o[0] - mm * cc.x) + bb.x); o[1] = gelu_erf(rs * (o[1] - mm * cc.y) + bb.y);
         o[2] = gelu_erf(rs * (o[2] - mm * cc.z) + bb.z); o[3] = gelu_erf(rs * (o[3] - mm * cc.w) + bb.w);
         st_out(a.out + ((long long)(n >> 3) * 2 + (m >> 5)) * 64 + (m & 31) + 32 * ((n >> 2) & 1), make_float4(o[0], o[1], o[2], o[3]));
