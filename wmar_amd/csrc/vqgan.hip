@@ -339,31 +339,35 @@ __global__ __launch_bounds__(COT * 64) void k_conv(ConvArgs a) {
 // 3 + 6 operand loads and 12 MFMAs of 32 cycles, against 16 MFMAs of 64 cycles in k_conv.
 constexpr int CONV_PSTRIDE_BX = 208;   // bytes per staged pixel
 
-template <int COT, int KS>
+// PT = pixel tiles of 32 per wave: 2 (an 8 x 8 output block) or 4 (round 5: two blocks side by side, 8 x 16) -- every weight operand
+// then feeds 24 MFMAs instead of 12 (the weights stream from L2 at half the rate per MFMA) and a wave has four independent accumulators.
+template <int COT, int KS, int PT = 2>
 __global__ __launch_bounds__(COT * 64) void k_conv_bx(ConvArgs a) {
+    static_assert(PT == 2 || PT == 4, "two or four pixel tiles per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char patchb[];  // [2][PH*PW][CONV_PSTRIDE_BX]
     constexpr int T = KS * KS, NIT = 2 * T;      // (tap, 16-channel half) steps per 32-channel round
-    constexpr int PW = 7 + KS, PH = PW;          // stride 1 only (host)
+    constexpr int PW = (PT == 4 ? 15 : 7) + KS, PH = 7 + KS;          // stride 1 only (host)
     // register rings: weights WR - 1 steps ahead (L2), patch operands one (LDS); a step's slot is its index in the round modulo the
     // ring, so the ring length must divide the steps of a round for the prefetch across the round boundary to land in the right slot
     constexpr int WR = NIT % 3 == 0 ? 3 : 2, XR = 2;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int bid = blockIdx.x;
-    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int tiles_xw = PT == 4 ? a.tiles_x >> 1 : a.tiles_x;      // workgroup tiles per row (host: tiles_x even for PT = 4)
+    const int tx = bid % tiles_xw; bid /= tiles_xw;
     const int ty = bid % a.tiles_y; bid /= a.tiles_y;
     const int cgroups = (a.CT + COT - 1) / COT;
     const int cg = bid % cgroups;
     const int b = bid / cgroups;
     const int ct = cg * COT + w;
     const bool active = ct < a.CT;
-    const int iy0 = ty * 8 - a.pad, ix0 = tx * 8 - a.pad;
+    const int iy0 = ty * 8 - a.pad, ix0 = tx * (PT == 4 ? 16 : 8) - a.pad;
     const int Hc = a.up ? a.Hs * 2 : a.Hs, Wc = a.up ? a.Ws * 2 : a.Ws;  // size the conv sees
     const int KU = a.Cin >> 4;
 
-    f32x16 acc[2];
+    f32x16 acc[PT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < PT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const int j = lane & 31, half = lane >> 5;
@@ -417,6 +421,15 @@ __global__ __launch_bounds__(COT * 64) void k_conv_bx(ConvArgs a) {
       const unsigned char* p0_ = (CUR) + lbase + (dy_ * PW + dx_) * CONV_PSTRIDE_BX + ((IT) & 1) * 32;            \
       const unsigned char* p1_ = p0_ + 4 * PW * CONV_PSTRIDE_BX;                                                 \
       xr[SLOT][0] = *(const u32x4*)p0_; xr[SLOT][1] = *(const u32x4*)(p0_ + 64); xr[SLOT][2] = *(const u32x4*)(p0_ + 128); \
+      xr[SLOT][3] = *(const u32x4*)p1_; xr[SLOT][4] = *(const u32x4*)(p1_ + 64); xr[SLOT][5] = *(const u32x4*)(p1_ + 128); \
+ }
+// PT = 4: the operands of ONE 8 x 8 block (HB = 0 left, 1 right) of step IT -- xr[0] / xr[1] hold the two blocks of the current step and
+// are refilled for the next step right behind their twelve MFMAs (half-step ring: 48 operand registers instead of 96)
+#define WMAR_CONVBX_LOADXH(SLOT, CUR, IT, HB)                                                                   \
+    { const int dy_ = ((IT) >> 1) / KS, dx_ = ((IT) >> 1) % KS;                                                  \
+      const unsigned char* p0_ = (CUR) + lbase + (dy_ * PW + dx_ + 8 * (HB)) * CONV_PSTRIDE_BX + ((IT) & 1) * 32; \
+      const unsigned char* p1_ = p0_ + 4 * PW * CONV_PSTRIDE_BX;                                                 \
+      xr[SLOT][0] = *(const u32x4*)p0_; xr[SLOT][1] = *(const u32x4*)(p0_ + 64); xr[SLOT][2] = *(const u32x4*)(p0_ + 128); \
       xr[SLOT][3] = *(const u32x4*)p1_; xr[SLOT][4] = *(const u32x4*)(p1_ + 64); xr[SLOT][5] = *(const u32x4*)(p1_ + 128); }
     // GroupNorm parameters of this thread's four channels (gamma, beta, the group's mean / rstd): they depend on the round only, so
     // they are requested a whole round ahead, in front of the patch -- inside the staging they were a dependent L2 round trip per
@@ -446,6 +459,33 @@ __global__ __launch_bounds__(COT * 64) void k_conv_bx(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < NPT; ++i) pr[i] = *(const float4*)(inb + (goff[i] >= 0 ? goff[i] : 0) + rn * CONV_CCH);   // unconditional; padding is zeroed when staged
         const unsigned char* cur = patchb + buf * psz;
+#define WMAR_CONVBX_ROUND6(XS, A0, A1)                                                                          \
+            WMAR_CONVBX_MFMA(wl, xr[XS][0], A0); WMAR_CONVBX_MFMA(wl, xr[XS][3], A1);                            \
+            WMAR_CONVBX_MFMA(wh, xr[XS][2], A0); WMAR_CONVBX_MFMA(wh, xr[XS][5], A1);                            \
+            WMAR_CONVBX_MFMA(wm, xr[XS][1], A0); WMAR_CONVBX_MFMA(wm, xr[XS][4], A1);                            \
+            WMAR_CONVBX_MFMA(wm, xr[XS][0], A0); WMAR_CONVBX_MFMA(wm, xr[XS][3], A1);                            \
+            WMAR_CONVBX_MFMA(wh, xr[XS][1], A0); WMAR_CONVBX_MFMA(wh, xr[XS][4], A1);                            \
+            WMAR_CONVBX_MFMA(wh, xr[XS][0], A0); WMAR_CONVBX_MFMA(wh, xr[XS][3], A1);
+        if (PT == 4) {
+            WMAR_CONVBX_LOADXH(0, cur, 0, 0)
+            WMAR_CONVBX_LOADXH(1, cur, 0, 1)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (it + WR - 1 < NIT) { WMAR_CONVBX_LOADW((it + WR - 1) % WR, r, it + WR - 1) }
+                else { WMAR_CONVBX_LOADW((it + WR - 1) % WR, rn, it + WR - 1 - NIT) }
+                __builtin_amdgcn_sched_barrier(0);
+                const u32x4 wh = wr[it % WR][0], wm = wr[it % WR][1], wl = wr[it % WR][2];
+                WMAR_CONVBX_ROUND6(0, acc[0], acc[1])                       // the small products first
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + 1 < NIT) { WMAR_CONVBX_LOADXH(0, cur, it + 1, 0) }
+                __builtin_amdgcn_sched_barrier(0);
+                WMAR_CONVBX_ROUND6(1, acc[PT - 2], acc[PT - 1])
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + 1 < NIT) { WMAR_CONVBX_LOADXH(1, cur, it + 1, 1) }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
         WMAR_CONVBX_LOADX(0, cur, 0)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -456,17 +496,11 @@ __global__ __launch_bounds__(COT * 64) void k_conv_bx(ConvArgs a) {
             if (it + 1 < NIT) { WMAR_CONVBX_LOADX((it + 1) % XR, cur, it + 1) }
             __builtin_amdgcn_sched_barrier(0);
             const u32x4 wh = wr[it % WR][0], wm = wr[it % WR][1], wl = wr[it % WR][2];
-            const u32x4 x0h = xr[it % XR][0], x0m = xr[it % XR][1], x0l = xr[it % XR][2];
-            const u32x4 x1h = xr[it % XR][3], x1m = xr[it % XR][4], x1l = xr[it % XR][5];
-            // the small products first
-            WMAR_CONVBX_MFMA(wl, x0h, acc[0]); WMAR_CONVBX_MFMA(wl, x1h, acc[1]);
-            WMAR_CONVBX_MFMA(wh, x0l, acc[0]); WMAR_CONVBX_MFMA(wh, x1l, acc[1]);
-            WMAR_CONVBX_MFMA(wm, x0m, acc[0]); WMAR_CONVBX_MFMA(wm, x1m, acc[1]);
-            WMAR_CONVBX_MFMA(wm, x0h, acc[0]); WMAR_CONVBX_MFMA(wm, x1h, acc[1]);
-            WMAR_CONVBX_MFMA(wh, x0m, acc[0]); WMAR_CONVBX_MFMA(wh, x1m, acc[1]);
-            WMAR_CONVBX_MFMA(wh, x0h, acc[0]); WMAR_CONVBX_MFMA(wh, x1h, acc[1]);
+            WMAR_CONVBX_ROUND6(it % XR, acc[0], acc[1])                     // the small products first
             __builtin_amdgcn_sched_barrier(0);
         }
+        }
+#undef WMAR_CONVBX_ROUND6
         if (more) {
             unsigned char* nxt = patchb + (buf ^ 1) * psz;
             WMAR_CONVBX_STAGE(nxt, (r + 1) * CONV_CCH)
@@ -479,8 +513,14 @@ __global__ __launch_bounds__(COT * 64) void k_conv_bx(ConvArgs a) {
 #undef WMAR_CONVBX_MFMA
 #undef WMAR_CONVBX_LOADW
 #undef WMAR_CONVBX_LOADX
+#undef WMAR_CONVBX_LOADXH
     if (!active) return;
-    conv_store(a, acc, b, ct, ty, tx, lane);
+    if (PT == 4) {
+        conv_store(a, *reinterpret_cast<const f32x16(*)[2]>(&acc[0]), b, ct, ty, 2 * tx, lane);
+        conv_store(a, *reinterpret_cast<const f32x16(*)[2]>(&acc[PT - 2]), b, ct, ty, 2 * tx + 1, lane);
+    } else {
+        conv_store(a, *reinterpret_cast<const f32x16(*)[2]>(&acc[0]), b, ct, ty, tx, lane);
+    }
 }
 
 // ------------------------------------------------------------------------ GroupNorm
@@ -935,6 +975,7 @@ bool in_attn_res(const wmar_vq_config& c, int res) {
 
 // WMAR_CONV_NO_BX=1 (read once, any build): keep every convolution on the fp32-input MFMA.  The bf16-piece split turns an infinite
 // operand into NaN (inf - inf) where fp32 arithmetic gives +-inf (bx_split.h): a model with non-finite activations can opt out.
+static bool conv_pt4() { static int v = -1; if (v < 0) { const char* e = getenv("WMAR_CONV_PT"); v = (e && atoi(e) == 2) ? 0 : 1; } return v != 0; }
 static bool conv_no_bx() { static int v = -1; if (v < 0) v = getenv("WMAR_CONV_NO_BX") ? 1 : 0; return v != 0; }
 #ifdef WMAR_DEV_KNOBS
 static bool vq_trace() { static int v = -1; if (v < 0) { const char* e = getenv("WMAR_VQ_TRACE"); v = e ? atoi(e) : 0; } return v != 0; }
@@ -982,12 +1023,20 @@ int run_conv(const ConvW& c, const float* in, float* out, const float* res, int 
     // k_conv_bx stages (PW * PW * 8) / threads float4 per thread: up to 13 (one wave per workgroup: the 128 -> 3 output conv)
     const bool bx = c.wq && c.cin_s % CONV_CCH == 0 && stride == 1 && (c.ks == 3 || c.ks == 1) && !conv_no_bx();
     if (bx) a.dbuf = 1;
-    const size_t lds = bx ? (size_t)2 * PW * PW * CONV_PSTRIDE_BX : (size_t)(a.dbuf ? 2 : 1) * PW * PW * CONV_PSTRIDE * sizeof(float);
+    // 8 x 16 output pixels per workgroup (four pixel tiles per wave) for the wide 3 x 3 convolutions on the bf16 pipe: WMAR_CONV_PT=2 keeps 8 x 8 (A/B)
+    const bool wide = bx && COT == 4 && c.ks == 3 && a.tiles_x % 2 == 0 && wq_bstride == 0 && conv_pt4();
+    const size_t lds = bx ? (size_t)2 * PW * (wide ? PW + 8 : PW) * CONV_PSTRIDE_BX : (size_t)(a.dbuf ? 2 : 1) * PW * PW * CONV_PSTRIDE * sizeof(float);
     const int cgroups = (c.CT + COT - 1) / COT;
-    const unsigned grid = (unsigned)((long long)B * cgroups * a.tiles_x * a.tiles_y);
+    const unsigned grid = (unsigned)((long long)B * cgroups * (wide ? a.tiles_x / 2 : a.tiles_x) * a.tiles_y);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (vq_trace()) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
-    if (bx && COT == 4 && c.ks == 3) hipLaunchKernelGGL((k_conv_bx<4, 3>), dim3(grid), dim3(256), lds, st, a);
+    if (wide) {
+        // 75 KB of dynamic LDS (two 10 x 18-pixel patches): above the 64 KB a kernel gets without asking
+        static const hipError_t lds_ok = hipFuncSetAttribute((const void*)k_conv_bx<4, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        WMAR_REQUIRE(lds_ok == hipSuccess, "k_conv_bx: raising the dynamic LDS limit failed: %s", hipGetErrorString(lds_ok));
+        hipLaunchKernelGGL((k_conv_bx<4, 3, 4>), dim3(grid), dim3(256), lds, st, a);
+    }
+    else if (bx && COT == 4 && c.ks == 3) hipLaunchKernelGGL((k_conv_bx<4, 3>), dim3(grid), dim3(256), lds, st, a);
     else if (bx && COT == 4) hipLaunchKernelGGL((k_conv_bx<4, 1>), dim3(grid), dim3(256), lds, st, a);
     else if (bx && COT == 2 && c.ks == 3) hipLaunchKernelGGL((k_conv_bx<2, 3>), dim3(grid), dim3(128), lds, st, a);
     else if (bx && COT == 2) hipLaunchKernelGGL((k_conv_bx<2, 1>), dim3(grid), dim3(128), lds, st, a);
