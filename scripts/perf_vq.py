@@ -1,7 +1,7 @@
 """Dev tool: time the full-size Taming VQGAN decode/encode (random weights)."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("WMAR_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wmar_amd.utils import synth
 from wmar_amd.models.engine import VQGANEngine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16

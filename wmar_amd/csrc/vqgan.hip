@@ -341,12 +341,14 @@ constexpr int CONV_PSTRIDE_BX = 208;   // bytes per staged pixel
 
 // PT = pixel tiles of 32 per wave: 2 (an 8 x 8 output block) or 4 (round 5: two blocks side by side, 8 x 16) -- every weight operand
 // then feeds 24 MFMAs instead of 12 (the weights stream from L2 at half the rate per MFMA) and a wave has four independent accumulators.
-template <int COT, int KS, int PT = 2>
+// STRIDE = 2 (round 5): the downsampling convolutions (3 x 3, stride 2, asymmetric zero pad (0, 1, 0, 1): model.py:69-73) on the same
+// pipe -- a 17 x 17-pixel patch per 8 x 8 outputs (two buffers = 120 KB of LDS, one workgroup per CU), operands read two pixels apart.
+template <int COT, int KS, int PT = 2, int STRIDE = 1>
 __global__ __launch_bounds__(COT * 64) void k_conv_bx(ConvArgs a) {
-    static_assert(PT == 2 || PT == 4, "two or four pixel tiles per wave");
+    static_assert(PT == 2 || (PT == 4 && STRIDE == 1), "two pixel tiles per wave, or four at stride 1");
     extern __shared__ __attribute__((aligned(16))) unsigned char patchb[];  // [2][PH*PW][CONV_PSTRIDE_BX]
     constexpr int T = KS * KS, NIT = 2 * T;      // (tap, 16-channel half) steps per 32-channel round
-    constexpr int PW = (PT == 4 ? 15 : 7) + KS, PH = 7 + KS;          // stride 1 only (host)
+    constexpr int PW = (PT == 4 ? 15 : 7) * STRIDE + KS, PH = 7 * STRIDE + KS;
     // register rings: weights WR - 1 steps ahead (L2), patch operands one (LDS); a step's slot is its index in the round modulo the
     // ring, so the ring length must divide the steps of a round for the prefetch across the round boundary to land in the right slot
     constexpr int WR = NIT % 3 == 0 ? 3 : 2, XR = 2;
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(COT * 64) void k_conv_bx(ConvArgs a) {
     const int b = bid / cgroups;
     const int ct = cg * COT + w;
     const bool active = ct < a.CT;
-    const int iy0 = ty * 8 - a.pad, ix0 = tx * (PT == 4 ? 16 : 8) - a.pad;
+    const int iy0 = ty * 8 * STRIDE - a.pad, ix0 = tx * (PT == 4 ? 16 : 8) * STRIDE - a.pad;
     const int Hc = a.up ? a.Hs * 2 : a.Hs, Wc = a.up ? a.Ws * 2 : a.Ws;  // size the conv sees
     const int KU = a.Cin >> 4;
 
@@ -415,11 +417,11 @@ __global__ __launch_bounds__(COT * 64) void k_conv_bx(ConvArgs a) {
 #define WMAR_CONVBX_LOADW(SLOT, R, IT)                                                                          \
     { const u32x4* wp_ = wtile + ((long long)((IT) >> 1) * KU + 2 * (R) + ((IT) & 1)) * 192;                       \
       wr[SLOT][0] = wp_[0]; wr[SLOT][1] = wp_[64]; wr[SLOT][2] = wp_[128]; }
-    const int lbase = (prow * PW + pcol) * CONV_PSTRIDE_BX + half * 16;
+    const int lbase = (prow * STRIDE * PW + pcol * STRIDE) * CONV_PSTRIDE_BX + half * 16;
 #define WMAR_CONVBX_LOADX(SLOT, CUR, IT)                                                                        \
     { const int dy_ = ((IT) >> 1) / KS, dx_ = ((IT) >> 1) % KS;                                                  \
       const unsigned char* p0_ = (CUR) + lbase + (dy_ * PW + dx_) * CONV_PSTRIDE_BX + ((IT) & 1) * 32;            \
-      const unsigned char* p1_ = p0_ + 4 * PW * CONV_PSTRIDE_BX;                                                 \
+      const unsigned char* p1_ = p0_ + 4 * STRIDE * PW * CONV_PSTRIDE_BX;                                                 \
       xr[SLOT][0] = *(const u32x4*)p0_; xr[SLOT][1] = *(const u32x4*)(p0_ + 64); xr[SLOT][2] = *(const u32x4*)(p0_ + 128); \
       xr[SLOT][3] = *(const u32x4*)p1_; xr[SLOT][4] = *(const u32x4*)(p1_ + 64); xr[SLOT][5] = *(const u32x4*)(p1_ + 128); \
  }
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(COT * 64) void k_conv_bx(ConvArgs a) {
 #define WMAR_CONVBX_LOADXH(SLOT, CUR, IT, HB)                                                                   \
     { const int dy_ = ((IT) >> 1) / KS, dx_ = ((IT) >> 1) % KS;                                                  \
       const unsigned char* p0_ = (CUR) + lbase + (dy_ * PW + dx_ + 8 * (HB)) * CONV_PSTRIDE_BX + ((IT) & 1) * 32; \
-      const unsigned char* p1_ = p0_ + 4 * PW * CONV_PSTRIDE_BX;                                                 \
+      const unsigned char* p1_ = p0_ + 4 * STRIDE * PW * CONV_PSTRIDE_BX;                                                 \
       xr[SLOT][0] = *(const u32x4*)p0_; xr[SLOT][1] = *(const u32x4*)(p0_ + 64); xr[SLOT][2] = *(const u32x4*)(p0_ + 128); \
       xr[SLOT][3] = *(const u32x4*)p1_; xr[SLOT][4] = *(const u32x4*)(p1_ + 64); xr[SLOT][5] = *(const u32x4*)(p1_ + 128); }
     // GroupNorm parameters of this thread's four channels (gamma, beta, the group's mean / rstd): they depend on the round only, so
@@ -975,6 +977,7 @@ bool in_attn_res(const wmar_vq_config& c, int res) {
 
 // WMAR_CONV_NO_BX=1 (read once, any build): keep every convolution on the fp32-input MFMA.  The bf16-piece split turns an infinite
 // operand into NaN (inf - inf) where fp32 arithmetic gives +-inf (bx_split.h): a model with non-finite activations can opt out.
+static bool conv_s2_bx() { static int v = -1; if (v < 0) { const char* e = getenv("WMAR_CONV_S2_FP32"); v = e ? 0 : 1; } return v != 0; }      // A/B: WMAR_CONV_S2_FP32=1 keeps k_conv
 static bool conv_pt4() { static int v = -1; if (v < 0) { const char* e = getenv("WMAR_CONV_PT"); v = (e && atoi(e) == 2) ? 0 : 1; } return v != 0; }
 static bool conv_no_bx() { static int v = -1; if (v < 0) v = getenv("WMAR_CONV_NO_BX") ? 1 : 0; return v != 0; }
 #ifdef WMAR_DEV_KNOBS
@@ -1021,16 +1024,21 @@ int run_conv(const ConvW& c, const float* in, float* out, const float* res, int 
     if (stats) { a.st_part = g_trk.part; a.st_cpg = cpg_out; g_trk.src = out; g_trk.tiles = a.tiles_x * a.tiles_y; g_trk.C = c.cout; }
     else if (g_trk.src == out) g_trk.src = nullptr;      // the tensor the buffer described is being overwritten
     // k_conv_bx stages (PW * PW * 8) / threads float4 per thread: up to 13 (one wave per workgroup: the 128 -> 3 output conv)
-    const bool bx = c.wq && c.cin_s % CONV_CCH == 0 && stride == 1 && (c.ks == 3 || c.ks == 1) && !conv_no_bx();
+    const bool bx2 = c.wq && c.cin_s % CONV_CCH == 0 && stride == 2 && c.ks == 3 && COT == 4 && !up && !conv_no_bx() && conv_s2_bx();   // downsampling convs
+    const bool bx = (c.wq && c.cin_s % CONV_CCH == 0 && stride == 1 && (c.ks == 3 || c.ks == 1) && !conv_no_bx()) || bx2;
     if (bx) a.dbuf = 1;
     // 8 x 16 output pixels per workgroup (four pixel tiles per wave) for the wide 3 x 3 convolutions on the bf16 pipe: WMAR_CONV_PT=2 keeps 8 x 8 (A/B)
-    const bool wide = bx && COT == 4 && c.ks == 3 && a.tiles_x % 2 == 0 && wq_bstride == 0 && conv_pt4();
+    const bool wide = bx && !bx2 && COT == 4 && c.ks == 3 && a.tiles_x % 2 == 0 && wq_bstride == 0 && conv_pt4();
     const size_t lds = bx ? (size_t)2 * PW * (wide ? PW + 8 : PW) * CONV_PSTRIDE_BX : (size_t)(a.dbuf ? 2 : 1) * PW * PW * CONV_PSTRIDE * sizeof(float);
     const int cgroups = (c.CT + COT - 1) / COT;
     const unsigned grid = (unsigned)((long long)B * cgroups * (wide ? a.tiles_x / 2 : a.tiles_x) * a.tiles_y);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (vq_trace()) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
-    if (wide) {
+    if (bx2) {
+        static const hipError_t lds2_ok = hipFuncSetAttribute((const void*)k_conv_bx<4, 3, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        WMAR_REQUIRE(lds2_ok == hipSuccess, "k_conv_bx (stride 2): raising the dynamic LDS limit failed: %s", hipGetErrorString(lds2_ok));
+        hipLaunchKernelGGL((k_conv_bx<4, 3, 2, 2>), dim3(grid), dim3(256), lds, st, a);
+    } else if (wide) {
         // 75 KB of dynamic LDS (two 10 x 18-pixel patches): above the 64 KB a kernel gets without asking
         static const hipError_t lds_ok = hipFuncSetAttribute((const void*)k_conv_bx<4, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         WMAR_REQUIRE(lds_ok == hipSuccess, "k_conv_bx: raising the dynamic LDS limit failed: %s", hipGetErrorString(lds_ok));
