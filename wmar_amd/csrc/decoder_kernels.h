@@ -1376,7 +1376,7 @@ struct BxArgs {
     int KU;                    // K / 16
     int S;                     // K slices: KU == 4 * PER * S
     // GELU variant (S == 1): out is not written; gelu(sum + bias) goes out as bf16 pieces for the next k_bx GEMM
-    const float* bias;         // [N]
+    const float* bias;         // [N]; without GELU: nullable, added to the slab (S == 1: finished values)
     u32x4* outq;               // planes [N/16][MTW][3][64]
 };
 
@@ -1470,6 +1470,10 @@ __global__ __launch_bounds__(256) void k_bx(BxArgs a) {
             v = make_float4(gelu_erf(v.x + bb.x), gelu_erf(v.y + bb.y), gelu_erf(v.z + bb.z), gelu_erf(v.w + bb.w));
             bx_store_planes4(a.outq, MTW, kb, hf, i, lane & 31, v);
         } else {
+            if (a.bias) {       // (round 5: RAR's adaLN GEMM -- the whole K in one slice, finished values)
+                const float4 bb = *(const float4*)(a.bias + ((grp * NT + t) * 4 + g) * 8 + 4 * (lane >> 5));
+                v = make_float4(v.x + bb.x, v.y + bb.y, v.z + bb.z, v.w + bb.w);
+            }
             st_out(out + ((long long)((grp * NT + t) * 4 + g) * MTW + i) * 64 + lane, v);
         }
     }

@@ -29,6 +29,7 @@ namespace wmar {
 // sc = SiLU(emb[cond] + timesteps[p])   (forward_fn, rar.py:346-384)
 struct RarEmbedArgs {
     float4* x; float4* sc; double* stats;
+    u32x4* scq;              // nullable: SiLU(c) as bf16 pieces as well (the adaLN GEMM on the bf16 pipe)
     const float* emb;        // [n_embeddings][d]
     const float* cls;        // [d]
     const float* pos; const float* tape; const float* tstep;   // [*][d]
@@ -81,7 +82,10 @@ static __global__ __launch_bounds__(256) void k_rar_embed(RarEmbedArgs a) {
         float cv[4] = {ce.x + te.x, ce.y + te.y, ce.z + te.z, ce.w + te.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) cv[j] = cv[j] / (1.0f + expf(-cv[j]));   // SiLU
-        if (mt < a.MTsc) a.sc[((long long)kb * a.MTsc + mt) * 64 + lane] = make_float4(cv[0], cv[1], cv[2], cv[3]);
+        if (mt < a.MTsc) {
+            a.sc[((long long)kb * a.MTsc + mt) * 64 + lane] = make_float4(cv[0], cv[1], cv[2], cv[3]);
+            if (a.scq) bx_store_planes4(a.scq, a.MTsc, kb, half, mt, lane & 31, make_float4(cv[0], cv[1], cv[2], cv[3]));
+        }
     }
     red[w][lane][0] = s; red[w][lane][1] = ss;       // all 64 lanes, no shuffle (decoder_kernels.h, k_qkvx_bx's keeper reduction)
     __syncthreads();
@@ -404,6 +408,9 @@ struct wmar_rar {
     std::vector<RarLayer> layers;
     float *emb = nullptr, *cls = nullptr, *pos = nullptr, *tape = nullptr, *tstep = nullptr;
     float4 *wada = nullptr, *whead = nullptr;
+    float4* wada_bx = nullptr;     // the adaLN weights in k_pack_bx order (64 conditional rows: the GEMM runs as k_bx<4, 20, 2>)
+    u32x4* scq = nullptr;          // SiLU(c) of the conditional rows as bf16 pieces
+    bool bx_ada = false;
     float *bada = nullptr, *bhead = nullptr;
     // workspaces
     float4 *x = nullptr, *h = nullptr, *y = nullptr, *hbuf = nullptr, *sc = nullptr, *slabs = nullptr, *qkv_slabs = nullptr;
@@ -484,11 +491,23 @@ struct RarPlan {
         e.x = g->x; e.sc = g->sc; e.stats = g->stats; e.emb = g->emb; e.cls = g->cls; e.pos = g->pos; e.tape = g->tape;
         e.tstep = g->tstep; e.tok = tok; e.cond = g->cond_ids; e.ids = g->ids; e.ids_stride = g->cfg.image_seq_len;
         e.pos_dev = g->ctr; e.KB = KBD; e.MT = MT; e.n_chunks = nch; e.M = M; e.Bhalf = Bhalf; e.K = D; e.MTsc = MTc;
+        e.scq = ada_bx() ? g->scq : nullptr;
         hipLaunchKernelGGL(k_rar_embed, dim3(nch * MT), dim3(256), 0, st, e);
         return launch_status("k_rar_embed");
     }
     // all adaLN modulations of this position: mod[M][Ntot] = SiLU(c) W_ada^T + b_ada
+    // 33..64 adaLN rows at hidden size 1280: on the bf16 pipe (round 5)
+    bool ada_bx() const { return g->bx_ada && MTc == 2; }
     int adaln() {
+        if (ada_bx()) {
+            // k_bx<4, 20, 2>: 128 columns x the whole K per workgroup (1940 workgroups), its four waves a K quarter each; weights fp32
+            // (split in registers), SiLU(c) as pieces from k_rar_embed, bias in the epilogue, output in the packed layout the
+            // modulation consumers read.  The fp32-input MFMA GEMM it replaces was bound by that pipe (259 us at peak for
+            // 40.7 GFLOP, 381 measured); here the 1.27 GB weight stream is (159 us at 8 TB/s).
+            BxArgs x{};
+            x.Wq = g->wada_bx; x.Xq = g->scq; x.out = (float4*)g->mod; x.slab_stride = 0; x.KU = D / 16; x.S = 1; x.bias = g->bada;
+            return launch_bx<4, 20, 2, false>(x, (int)g->Ntot, st);
+        }
         GemmArgs a = base();
         a.Wp = g->wada; a.Xp = g->sc; a.KB = KBD; a.NT = (int)(g->Ntot / 32); a.bias = g->bada;
         a.out_packed = (float4*)g->mod; a.slab_stride = 0;        // packed [Ntot/8][MTc][64]: read like an activation by k_modulate / k_resid_mod
@@ -688,6 +707,9 @@ int wmar_rar_create(const wmar_rar_config* cfg, const char* const* names, const 
         TRY(copy_vec(g, &g->bhead, hb, (size_t)V, st));
         TRY(g->alloc(&g->wada, (size_t)g->Ntot * D / 4));
         TRY(g->alloc(&g->bada, (size_t)g->Ntot));
+        // WMAR_RAR_ADA_FP32=1 (A/B) keeps the per-step adaLN GEMM on the fp32-input MFMA
+        g->bx_ada = D == 1280 && g->Ntot % 128 == 0 && g->MTmax >= 2 && getenv("WMAR_NO_BX") == nullptr && getenv("WMAR_RAR_ADA_FP32") == nullptr;
+        if (g->bx_ada) { TRY(g->alloc(&g->wada_bx, (size_t)g->Ntot * D / 4)); TRY(g->alloc(&g->scq, (size_t)D / 16 * 2 * 3 * 64)); }
     }
     if (g->MTmax >= 4 && D % 32 == 0 && F % 32 == 0) {
         g->bx_qkv = bx_shape(3 * D / 64, D / 16); g->bx_proj = bx_shape(D / 32, D / 16); g->bx_fc2 = bx_shape(D / 64, F / 16);
@@ -733,12 +755,22 @@ int wmar_rar_create(const wmar_rar_config* cfg, const char* const* names, const 
         TRY(copy_vec(g, &w.knw, knw, (size_t)hd, st)); TRY(copy_vec(g, &w.knb, knb, (size_t)hd, st));
         // this block's 6d adaLN rows go to their slice of the one big modulation GEMM
         TRY(pack(aw, g->wada, 6 * D, D, l * (6 * D / 32), st));
+        if (g->bx_ada && rc == WMAR_OK) {
+            const long long total = (long long)(6 * D / 32) * (D / 16) * 128;
+            hipLaunchKernelGGL(k_pack_bx, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, aw, (const float*)nullptr, g->wada_bx, 6 * D, D, l * (6 * D / 32));
+            rc = launch_status("k_pack_bx");
+        }
         if (rc == WMAR_OK && hipMemcpyAsync(g->bada + (size_t)l * 6 * D, ab, (size_t)6 * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
             set_error("adaLN bias copy failed"); rc = WMAR_EHIP;
         }
     }
     if (rc == WMAR_OK) {
         TRY(pack(fw, g->wada, 2 * D, D, L * (6 * D / 32), st));
+        if (g->bx_ada && rc == WMAR_OK) {
+            const long long total = (long long)(2 * D / 32) * (D / 16) * 128;
+            hipLaunchKernelGGL(k_pack_bx, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, fw, (const float*)nullptr, g->wada_bx, 2 * D, D, L * (6 * D / 32));
+            rc = launch_status("k_pack_bx");
+        }
         if (rc == WMAR_OK && hipMemcpyAsync(g->bada + (size_t)L * 6 * D, fb, (size_t)2 * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
             set_error("final adaLN bias copy failed"); rc = WMAR_EHIP;
         }
@@ -794,6 +826,7 @@ int wmar_rar_create(const wmar_rar_config* cfg, const char* const* names, const 
         if (er == hipSuccess) er = hipMemsetAsync(g->h, 0, Mpad * D * 4, st);
         if (er == hipSuccess) er = hipMemsetAsync(g->y, 0, Mpad * D * 4, st);
         if (er == hipSuccess) er = hipMemsetAsync(g->sc, 0, Mpad * D * 4, st);
+        if (er == hipSuccess && g->scq) er = hipMemsetAsync(g->scq, 0, (size_t)D / 16 * 2 * 3 * 64 * 16, st);      // rows past the batch are never written
         if (er == hipSuccess) er = hipMemsetAsync(g->hbuf, 0, Mpad * F * 4, st);
         if (er == hipSuccess) er = hipMemsetAsync(g->mod, 0, Mpad * (size_t)g->Ntot * 4, st);
         if (er == hipSuccess) er = hipMemsetAsync(g->kcache, 0, kv * 4, st);
