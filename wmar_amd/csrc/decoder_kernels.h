@@ -1382,17 +1382,20 @@ struct BxArgs {
 
 #define WMAR_BX_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
 
-template <int NT, int PER, int MTW = 2, bool GELU = false>
-__global__ __launch_bounds__(256) void k_bx(BxArgs a) {
+// NW = waves per workgroup (4; 8 for RAR's FC1, round 5): the waves split the K slice, NW x PER x 16 k per workgroup.  A wave keeps one
+// step in flight beyond the one it computes, so a launch whose steps are bound by the latency of their loads takes PER x that latency:
+// twice the waves, half the steps.
+template <int NT, int PER, int MTW = 2, bool GELU = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void k_bx(BxArgs a) {
     // MTW row tiles of 32 (2: 64 rows, 4: 128 rows -- RAR under guidance); planes [K/16][MTW][3][64], slabs packed [N/8][MTW][64]
     constexpr int XR = 3 * MTW;             // 16-byte operand loads of a step
     constexpr int ROWS = NT * 4 * MTW;      // float4 rows (tile, row tile, register group) of the workgroup's output
-    __shared__ __attribute__((aligned(16))) float4 red[4][ROWS][64];
+    __shared__ __attribute__((aligned(16))) float4 red[NW][ROWS][64];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // slice = id % S: with S a multiple of 4 every XCD (id % 8) works on one or two K slices and keeps only those in its L2
     const int grp = (int)blockIdx.x / a.S, ks = (int)blockIdx.x % a.S;
-    const int u0 = (ks * 4 + w) * PER;
+    const int u0 = (ks * NW + w) * PER;
     f32x16 acc[NT][MTW];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -1459,11 +1462,13 @@ __global__ __launch_bounds__(256) void k_bx(BxArgs a) {
     // wave w sums rows w, w + 4, ... of the (tile, row tile, register group) rows over the four K quarters, in fixed order
     float4* out = a.out + (long long)ks * a.slab_stride;
 #pragma unroll
-    for (int r = 0; r < ROWS / 4; ++r) {
-        const int row = r * 4 + w, t = row / (4 * MTW), i = (row >> 2) % MTW, g = row & 3;
+    for (int r = 0; r < (ROWS + NW - 1) / NW; ++r) {
+        const int row = r * NW + w;
+        if (ROWS % NW != 0 && row >= ROWS) break;
+        const int t = row / (4 * MTW), i = (row >> 2) % MTW, g = row & 3;
         float4 v = red[0][row][lane];
 #pragma unroll
-        for (int o = 1; o < 4; ++o) { const float4 q = red[o][row][lane]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+        for (int o = 1; o < NW; ++o) { const float4 q = red[o][row][lane]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
         if (GELU) {
             const int kb = (grp * NT + t) * 4 + g, hf = lane >> 5;          // output features 8 kb + 4 hf .. + 3 = the next GEMM's k
             const float4 bb = *(const float4*)(a.bias + kb * 8 + 4 * hf);
@@ -1482,9 +1487,9 @@ __global__ __launch_bounds__(256) void k_bx(BxArgs a) {
 constexpr int BX_PER = 6;              // 16-k steps per wave: K slice = 4 waves x 6 x 16 = 384
 constexpr int BX_KSLICE = 4 * BX_PER * 16;
 // N must be a multiple of 32 * NT, K = S * 64 * PER; 32 * MTW rows
-template <int NT, int PER = BX_PER, int MTW = 2, bool GELU = false>
+template <int NT, int PER = BX_PER, int MTW = 2, bool GELU = false, int NW = 4>
 static int launch_bx(const BxArgs& a, int N, hipStream_t st) {
-    hipLaunchKernelGGL((k_bx<NT, PER, MTW, GELU>), dim3((unsigned)(N / (32 * NT) * a.S)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_bx<NT, PER, MTW, GELU, NW>), dim3((unsigned)(N / (32 * NT) * a.S)), dim3(NW * 64), 0, st, a);
     return launch_status("k_bx");
 }
 

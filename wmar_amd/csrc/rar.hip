@@ -618,7 +618,10 @@ struct RarPlan {
         if (fc1x) {
             BxArgs x{};
             x.Wq = w.wfc1_bx; x.Xq = g->xq; x.KU = D / 16; x.S = 1; x.bias = w.bfc1; x.outq = g->hq;
-            if ((rc = launch_bx<1, 20, 4, true>(x, g->F, st))) return rc;
+            // round 5: eight waves x 10 steps instead of four x 20 (WMAR_RAR_FC1_NW4=1: the round-2 form, A/B)
+            static const bool nw4 = getenv("WMAR_RAR_FC1_NW4") != nullptr;
+            if (nw4) { if ((rc = launch_bx<1, 20, 4, true>(x, g->F, st))) return rc; }
+            else if ((rc = launch_bx<1, 10, 4, true, 8>(x, g->F, st))) return rc;
         } else {
             GemmArgs f = base();
             f.Wp = w.wfc1; f.Xp = g->h; f.bias = w.bfc1; f.KB = KBD; f.NT = g->F / 32; f.out_packed = g->hbuf;
