@@ -25,8 +25,11 @@ res = {v: [] for v in variants}
 for r in range(rounds):
     for v in variants:
         env = dict(os.environ)
-        if v != "tree":
-            env["WMAR_ROOT"] = os.path.join(R, "build_alt", v)
+        name = v.split(":")[0]                      # "tree:WMAR_XR_NW8=1" = the working tree with that environment variable set
+        for kv in v.split(":")[1:]:
+            env[kv.split("=")[0]] = kv.split("=", 1)[1]
+        if name != "tree":
+            env["WMAR_ROOT"] = os.path.join(R, "build_alt", name)
         o = subprocess.run([sys.executable, "-c", CHILD, str(reps)], env=env, capture_output=True, text=True)
         line = [l for l in o.stdout.splitlines() if l.startswith("MS")]
         if not line:
@@ -34,4 +37,4 @@ for r in range(rounds):
         res[v] += [float(x) for x in line[0].split()[1:]]
 for v in variants:
     if res[v]:
-        print(f"{v:14s} min {min(res[v]):.4f}  median {statistics.median(res[v]):.4f}  max {max(res[v]):.4f} ms/step  (n={len(res[v])})")
+        print(f"{v:24s} min {min(res[v]):.4f}  median {statistics.median(res[v]):.4f}  max {max(res[v]):.4f} ms/step  (n={len(res[v])})")

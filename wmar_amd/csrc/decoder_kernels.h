@@ -1550,11 +1550,12 @@ __device__ __forceinline__ unsigned xcc_id() {
 }
 static __global__ void k_xcc_probe(unsigned* o) { if (threadIdx.x == 0) o[blockIdx.x] = xcc_id(); }
 
-template <int PER, int S>
-__global__ __launch_bounds__(256) void k_bx_xr(BxrArgs q) {
+// NW waves split the K slice in phase 1 (NW x PER x 16 k); phase 2 is the work of waves 0..3
+template <int PER, int S, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void k_bx_xr(BxrArgs q) {
     constexpr int MTW = 2, XR = 3 * MTW, ROWS = 4 * MTW;
     const BxArgs& a = q.bx;
-    __shared__ __attribute__((aligned(16))) float4 red[4][ROWS][64];
+    __shared__ __attribute__((aligned(16))) float4 red[NW][ROWS][64];
     __shared__ double sred[4][64][2];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1569,7 +1570,7 @@ __global__ __launch_bounds__(256) void k_bx_xr(BxrArgs q) {
     }
     // ---------------------------------------------------------------------------------------------------- phase 1 (k_bx<1, PER>)
     {
-        const int u0 = (ks * 4 + w) * PER;
+        const int u0 = (ks * NW + w) * PER;
         f32x16 acc[MTW];
 #pragma unroll
         for (int i = 0; i < MTW; ++i)
@@ -1621,11 +1622,11 @@ __global__ __launch_bounds__(256) void k_bx_xr(BxrArgs q) {
         __syncthreads();
         float4* out = a.out + (long long)ks * a.slab_stride;
 #pragma unroll
-        for (int r = 0; r < ROWS / 4; ++r) {
-            const int row = r * 4 + w, i = row >> 2, g = row & 3;
+        for (int r = 0; r < ROWS / NW; ++r) {
+            const int row = r * NW + w, i = row >> 2, g = row & 3;
             float4 v = red[0][row][lane];
 #pragma unroll
-            for (int o = 1; o < 4; ++o) { const float4 z = red[o][row][lane]; v.x += z.x; v.y += z.y; v.z += z.z; v.w += z.w; }
+            for (int o = 1; o < NW; ++o) { const float4 z = red[o][row][lane]; v.x += z.x; v.y += z.y; v.z += z.z; v.w += z.w; }
             out[((long long)(tile * 4 + g) * MTW + i) * 64 + lane] = v;
         }
     }
@@ -1672,7 +1673,7 @@ __global__ __launch_bounds__(256) void k_bx_xr(BxrArgs q) {
         const int kb_first = (grp * 2 + hp) * nkb;
         const int half = lane >> 5;
         double s = 0.0, ss = 0.0;
-        for (int k0 = w; k0 < nkb; k0 += 12) {
+        for (int k0 = w; k0 < nkb && w < 4; k0 += 12) {
             float4 v[3], sl[3][S], bb[3];
 #pragma unroll
             for (int e = 0; e < 3; ++e) {
@@ -1697,7 +1698,7 @@ __global__ __launch_bounds__(256) void k_bx_xr(BxrArgs q) {
                 ss += sq4_f64(r);         // never a v_fmac_f64 chain: common.h
             }
         }
-        sred[w][lane][0] = s; sred[w][lane][1] = ss;
+        if (w < 4) { sred[w][lane][0] = s; sred[w][lane][1] = ss; }
         __syncthreads();
         if (threadIdx.x < 32) {
             double ts = 0, tss = 0;
@@ -1709,9 +1710,9 @@ __global__ __launch_bounds__(256) void k_bx_xr(BxrArgs q) {
     WMAR_ST_END(q.trace, blockIdx.x)
 }
 
-template <int PER, int S>
+template <int PER, int S, int NW = 4>
 static int launch_bx_xr(const BxrArgs& q, int N, hipStream_t st) {
-    hipLaunchKernelGGL((k_bx_xr<PER, S>), dim3((unsigned)(N / 32 * S)), dim3(256), 0, st, q);
+    hipLaunchKernelGGL((k_bx_xr<PER, S, NW>), dim3((unsigned)(N / 32 * S)), dim3(NW * 64), 0, st, q);
     return launch_status("k_bx_xr");
 }
 

@@ -358,7 +358,10 @@ struct StepPlan {
             q.tiles_per_group = D / 32 / 8;
             q.trace = g->stamp_slot(l, 2);
             g->span_begin(WMAR_T_PROJ, st);
-            const int rc = launch_bx_xr<BX_PER, 4>(q, D, st);
+            // round 5: eight waves x 3 steps in phase 1 (its steps are bound by the latency of their loads: 3.817 -> 3.796 ms per step,
+            // same-box A/B); WMAR_XR_NW4=1 keeps four waves x 6 steps
+            static const bool xr4 = getenv("WMAR_XR_NW4") != nullptr;
+            const int rc = xr4 ? launch_bx_xr<BX_PER, 4>(q, D, st) : launch_bx_xr<BX_PER / 2, 4, 8>(q, D, st);
             g->span_end(st);
             return rc;
         }
@@ -669,7 +672,7 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
         // ... and every workgroup of its grid must be resident at once: one per CU at least (a CU mask or a partition mode shrinks
         // what the runtime reports)
         int nb = 0, dev = 0, cus = 0;
-        if (ok) ok = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bx_xr<BX_PER, 4>, 256, 0) == hipSuccess && hipGetDevice(&dev) == hipSuccess &&
+        if (ok) ok = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bx_xr<BX_PER / 2, 4, 8>, 512, 0) == hipSuccess && hipGetDevice(&dev) == hipSuccess &&
                      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
                      (long long)nb * cus >= (long long)(D / 32) * 4;
         g->xcd_ok = ok;
@@ -797,7 +800,7 @@ int wmar_gpt_plan_info(wmar_gpt* g, int64_t B, char* buf, int64_t buf_len) {
     if (p.qkv_bx()) snprintf(qkv, sizeof qkv, "k_qkvx_bx<%d> (bf16 pipe, %d K slices)", S_in, p.S_qx);
     else if (p.S_qx > 0) snprintf(qkv, sizeof qkv, "k_qkvx<%d,%d> (fp32 MFMA, %d K slices)", p.MT, S_in, p.S_qx);
     else snprintf(qkv, sizeof qkv, "k_gemm<EPI_PACKED> (fp32 MFMA, %d K slices) after k_resid_stats", p.S_qkv);
-    if (p.proj_xr) snprintf(proj, sizeof proj, "k_bx_xr<%d,4> (bf16 pipe, 4 K slices + XCD-local reduction: residual fold and LN2 statistics inside)", BX_PER);
+    if (p.proj_xr) snprintf(proj, sizeof proj, "k_bx_xr<%d,4> (bf16 pipe, 4 K slices + XCD-local reduction: residual fold and LN2 statistics inside)", BX_PER);   // (eight waves x BX_PER / 2 steps since round 5)
     else if (p.proj_bx) snprintf(proj, sizeof proj, "k_bx<1,%d> (bf16 pipe, %d K slices)", BX_PER, p.S_proj);
     else snprintf(proj, sizeof proj, "k_gemm<EPI_PACKED> (fp32 MFMA, %d K slices)", p.S_proj);
     if (p.fc1_x()) snprintf(fc1, sizeof fc1, "k_fc1x (fp32 MFMA, 24-column tiles, whole K)");
