@@ -1077,53 +1077,13 @@ static __global__ void k_pack_bx(const float* __restrict__ W, const float* __res
     Wq[idx + (long long)tile_off * KU * 128] = v;
 }
 
-// Dev experiment (scripts/fmac_experiment.sh, profiles/r04_fmac64_experiment.md): the sums of squares of the keeper workgroups as the
-// round-2 code had them -- a chain of dependent v_fmac_f64 -- with an s_nop at one of two places.  QX_FMAC_EXP = 1: the old expression;
-// 2: s_nop 1 between the v_cvt_f64_f32 producers and the first multiply / fmac only; 3: s_nop 1 between the dependent fmacs only.
-// Undefined (every shipped build): sq4_f64, products outside the fused chain.
-#define WMAR_STR_(X) #X
-#define WMAR_STR(X) WMAR_STR_(X)
-#if defined(QX_FMAC_EXP) && QX_FMAC_EXP == 1
-__device__ __forceinline__ double qx_sq4_exp(const float4& r) { return (double)r.x * r.x + (double)r.y * r.y + (double)r.z * r.z + (double)r.w * r.w; }
-#define WMAR_QX_SQ4(R) qx_sq4_exp(R)
-#elif defined(QX_FMAC_EXP) && QX_FMAC_EXP == 2
-__device__ __forceinline__ double qx_sq4_exp(const float4& r) {
-    double d0 = (double)r.x, d1 = (double)r.y, d2 = (double)r.z, d3 = (double)r.w;
-    asm volatile("s_nop 1" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
-    return __builtin_fma(d3, d3, __builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0)));
-}
-#define WMAR_QX_SQ4(R) qx_sq4_exp(R)
-#elif defined(QX_FMAC_EXP) && QX_FMAC_EXP == 3
-__device__ __forceinline__ double qx_sq4_exp(const float4& r) {
-    const double d0 = (double)r.x, d1 = (double)r.y, d2 = (double)r.z, d3 = (double)r.w;
-    double t = d0 * d0;
-    asm volatile("s_nop 1" : "+v"(t));
-    t = __builtin_fma(d1, d1, t);
-    asm volatile("s_nop 1" : "+v"(t));
-    t = __builtin_fma(d2, d2, t);
-    asm volatile("s_nop 1" : "+v"(t));
-    t = __builtin_fma(d3, d3, t);
-    return t;
-}
-#define WMAR_QX_SQ4(R) qx_sq4_exp(R)
-#else
-#define WMAR_QX_SQ4(R) sq4_f64(R)
-#endif
-
 constexpr int QX_TR_STRIDE = 36;      // floats per row of the epilogue's transpose tile (32 + 4: 16-byte rows on distinct banks)
 template <int S_IN>
 __global__ __launch_bounds__(512) void k_qkvx_bx(QkvxArgs a) {
     constexpr int MTW = 2;
-#ifdef QX_PAD
-    asm volatile(".rept " WMAR_STR(QX_PAD) "\n\ts_nop 0\n\t.endr");      // dev: shifts the kernel's code by 4 QX_PAD bytes (scripts/fmac_experiment.sh)
-#endif
     __shared__ __attribute__((aligned(16))) u32x4 xq[2][2][MTW][3][64];      // [buffer][step][row tile][piece][lane]
     __shared__ __attribute__((aligned(16))) float tr_s[4][32 * QX_TR_STRIDE];   // epilogue: one 32 x 32 tile per multiplying wave
-#ifdef QX_OLD_RED
-    __shared__ double red[4][MTW][32][2];      // dev experiment: the round-2 reduction (64-bit __shfl_xor + lanes 0..31 publish)
-#else
     __shared__ double red[4][MTW][64][2];      // every lane publishes its own partial sums (see the note at the keeper's reduction)
-#endif
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
@@ -1184,7 +1144,7 @@ __global__ __launch_bounds__(512) void k_qkvx_bx(QkvxArgs a) {
             if (keeper && (CIDX) % a.nkeep == g) {                                                      \
                 a.x_out[((long long)SKB * MTW + i) * 64 + lane] = r;                                    \
                 sum[i] += (double)r.x + (double)r.y + (double)r.z + (double)r.w;                        \
-                sq[i] += WMAR_QX_SQ4(r);        /* never a v_fmac_f64 chain: common.h */                \
+                sq[i] += sq4_f64(r);        /* never a v_fmac_f64 chain: common.h */                \
             }                                                                                           \
         }                                                                                               \
     }
@@ -1216,24 +1176,14 @@ __global__ __launch_bounds__(512) void k_qkvx_bx(QkvxArgs a) {
             // fixed order (the same additions the 64-bit __shfl_xor(., 32) of earlier rounds made)
 #pragma unroll
             for (int i = 0; i < MTW; ++i) {
-#ifdef QX_OLD_RED
-                sum[i] += __shfl_xor(sum[i], 32);
-                sq[i] += __shfl_xor(sq[i], 32);
-                if (lane < 32) { red[sw][i][lane][0] = sum[i]; red[sw][i][lane][1] = sq[i]; }
-#else
                 red[sw][i][lane][0] = sum[i]; red[sw][i][lane][1] = sq[i];
-#endif
             }
             __syncthreads();                               // the multiplying waves meet it after their stores
             const int t = threadIdx.x - 256;
             if (t < 32 * MTW) {
                 const int i = t >> 5, r = t & 31;
                 double ts = 0, tss = 0;
-#ifdef QX_OLD_RED
-                for (int ww = 0; ww < 4; ++ww) { ts += red[ww][i][r][0]; tss += red[ww][i][r][1]; }
-#else
                 for (int ww = 0; ww < 4; ++ww) { ts += red[ww][i][r][0] + red[ww][i][r + 32][0]; tss += red[ww][i][r][1] + red[ww][i][r + 32][1]; }
-#endif
                 double* o = a.stats + ((long long)(s * a.nkeep + g) * (MTW * 32) + i * 32 + r) * 2;
                 o[0] = ts; o[1] = tss;
             }

@@ -42,11 +42,11 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
-// Block-wide order-independent reductions through LDS.
+// Block-wide order-independent reductions through LDS.  Every call site owns its slot `red` (SAMP_WAVES words nobody else
+// writes), so ONE barrier per reduction is enough: no wave can still be reading the slot from an earlier use.
 __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long* red) {
     v = wave_sum_u64(v);
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    __syncthreads();
     if (l == 0) red[w] = v;
     __syncthreads();
     unsigned long long s = 0;
@@ -57,7 +57,6 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
 __device__ __forceinline__ uint32_t block_max_u32(uint32_t v, unsigned long long* red) {
     for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    __syncthreads();
     if (l == 0) red[w] = v;
     __syncthreads();
     uint32_t s = 0;
@@ -65,7 +64,8 @@ __device__ __forceinline__ uint32_t block_max_u32(uint32_t v, unsigned long long
     return s;
 }
 
-// Wave 0 scans a 256-bucket u64 histogram.
+// One wave scans a 256-bucket u64 histogram (every wave of the sampler does, redundantly: the result is wave-uniform and no
+// broadcast through LDS -- two more workgroup barriers per pass -- is needed).
 //  DESC_COUNT: from bucket 255 downwards, first bucket where the running count reaches `need`;
 //              returns bucket, and *above = count strictly above it.
 //  ASC_MASS:   from bucket 0 upwards, first bucket whose inclusive mass (base + ...) converts to
@@ -104,7 +104,7 @@ __device__ __forceinline__ int scan_hist(const unsigned long long* hist, unsigne
         else if (c3 >= need) { hit = 3; before = c2; }
     }
     unsigned long long m = __ballot(hit >= 0);
-    if (m == 0) { *other = inc; return -1; }  // (only lane 63's value is the total; unused by callers)
+    if (m == 0) { *other = __shfl(inc, 0); return -1; }  // wave-uniform (lane 0's running sum, what wave 0 used to publish; no caller uses it)
     int first = __ffsll((long long)m) - 1;
     int hit_f = __shfl(hit, first);
     unsigned long long before_f = __shfl(before, first);
@@ -121,16 +121,27 @@ __device__ __forceinline__ int scan_hist(const unsigned long long* hist, unsigne
 // general path hipcc waits for each load on its own (`s_waitcnt vmcnt(0)` behind every one: ~48 serialized L2 round trips per row).
 template <int EPT, bool PLAIN = false>
 __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
-    __shared__ unsigned long long hist[256];
-    __shared__ unsigned long long red[SAMP_WAVES];
-    __shared__ unsigned long long sh_u64[2];
-    __shared__ int sh_i[2];
+    // One histogram per radix pass (4 top-k + 4 top-p + 4 tie-break), zeroed once up front, and one reduction slot per call site:
+    // a pass is count -> ONE barrier -> every wave scans the histogram itself (round 5; it was zero / barrier / count / barrier /
+    // wave 0 scans / barrier / read / barrier: ~46 sixteen-wave barriers per row, now 13).
+    constexpr int N_HIST = 12, N_RED = 5;
+    __shared__ unsigned long long hist_all[N_HIST][256];
+    __shared__ unsigned long long red_all[N_RED][SAMP_WAVES];
     __shared__ float red_f[SAMP_WAVES];
     __shared__ int red_i[SAMP_WAVES];
     // the noise row of rows that fit registers 16 values per thread (V <= 16384): requested in P0, parked here (64 KB: the
     // workgroup owns its CU) and read back for the final race -- held in registers through the passes it cost 30 spilled VGPRs
     // at the 128 the 1024-thread workgroup allows (round-3 review)
     __shared__ float q_lds[(EPT > 0 && EPT <= 16) ? EPT * SAMP_THREADS : 1];
+    // survivors of top-k compacted to one per thread (round 5): every pass behind top-k then costs one element per thread instead
+    // of a sweep over the EPT registers of which ~1.5 % are alive
+    __shared__ float surv_x[EPT > 0 ? SAMP_THREADS : 1];
+    __shared__ int surv_v[EPT > 0 ? SAMP_THREADS : 1];
+    __shared__ int surv_n;
+    if (threadIdx.x == 0) surv_n = 0;
+    static_assert(sizeof(hist_all) + sizeof(red_all) + sizeof(q_lds) + 2 * SAMP_WAVES * 4 + 2 * SAMP_THREADS * 4 + 4 <= 160 * 1024,
+                  "k_sample_fused: static LDS beyond the 160 KB of a gfx950 CU (the noise row alone is 64 KB: gfx950 only)");
+    for (int i = threadIdx.x; i < N_HIST * 256; i += SAMP_THREADS) (&hist_all[0][0])[i] = 0;      // visible after the row-max barrier
 
     const long long b = blockIdx.x;
     const long long V = a.V;
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
                 if (v < V) {
                     float xv = lv[j];
                     if (grow && ((gw[j] >> (v & 31)) & 1u)) xv = xv + delta;
-                    xv = xv / T;
+                    if (T != 1.0f) xv = xv / T;          // (x / 1 is x: ten instructions per value less)
                     xr[i] = xv;
                     if (a.scratch) x[v] = xv;
                     kmax = max(kmax, wmar_f32_key(xv));
@@ -263,33 +274,35 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
     }
     WMAR_PARK_Q()            // each thread reads back its own words: no barrier needed
 #undef WMAR_PARK_Q
-    kmax = block_max_u32(kmax, red);
+    kmax = block_max_u32(kmax, red_all[0]);
     const float m = wmar_key_f32(kmax);
     const uint32_t NEG_INF_KEY = 0x007fffffu;  // wmar_f32_key(-inf)
 
     // top-k: exact k-th largest key by 4 radix passes (count histograms)
     uint32_t thr_key = 0;
+    unsigned long long n_alive = ~0ull;      // keys >= thr_key when top-k is on (an upper bound: -inf keys are dropped below)
     if (a.top_k > 0 && (long long)a.top_k < V) {
         uint32_t prefix = 0, mask = 0;
         unsigned long long need = (unsigned long long)a.top_k;
         for (int pass = 3; pass >= 0; --pass) {
-            for (int i = tid; i < 256; i += SAMP_THREADS) hist[i] = 0;
-            __syncthreads();
+            unsigned long long* hist = hist_all[3 - pass];
             if (pass == 3) {
-                // The top byte (sign + 7 exponent bits) takes a handful of values: per-lane LDS
-                // atomics on the same bucket serialise, so each wave first counts its lanes per
-                // distinct digit (ballot) and issues ONE add per digit.
+                // The top byte (sign + 7 exponent bits) takes a handful of values.  Round 5: ONE de-duplication round per value --
+                // the lanes that share the first active lane's digit are counted by ballot and added once, the others issue a
+                // plain 32-bit LDS add (the LDS serialises equal addresses at a lane per cycle).  Rounds 1-4 looped the ballot
+                // once per distinct digit: ~12 iterations x 16 values, half of the kernel's VALU instructions.
 #define WMAR_TOPBYTE(V_, XV_)                                                                         \
                 {                                                                                         \
                     const bool active = (V_) < V;                                                         \
-                    const uint32_t d = active ? (wmar_f32_key(XV_) >> 24) : 0u;                           \
-                    unsigned long long todo = __ballot(active);                                           \
-                    while (todo) {                                                                        \
-                        const int leader = __ffsll((long long)todo) - 1;                                  \
+                    const uint32_t d = active ? (wmar_f32_key(XV_) >> 24) : 0xffffffffu;                  \
+                    const unsigned long long act = __ballot(active);                                      \
+                    if (act) {                                                                            \
+                        const int leader = __ffsll((long long)act) - 1;                                   \
                         const uint32_t dl = (uint32_t)__shfl((int)d, leader);                             \
-                        const unsigned long long same = __ballot(active && d == dl);                      \
-                        if ((tid & 63) == leader) atomicAdd(&hist[dl], (unsigned long long)__popcll(same)); \
-                        todo &= ~same;                                                                    \
+                        const unsigned long long same = __ballot(d == dl);                                \
+                        uint32_t* h32 = reinterpret_cast<uint32_t*>(hist);      /* counts < 2^32: low words */ \
+                        if ((tid & 63) == leader) atomicAdd(&h32[2 * dl], (uint32_t)__popcll(same));      \
+                        else if (active && d != dl) atomicAdd(&h32[2 * d], 1u);                           \
                     }                                                                                     \
                 }
                 if (EPT > 0) {       // (direct register access: selecting xr[i_] by a run-time i_ was an EPT^2 chain of v_cndmask)
@@ -314,20 +327,90 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
                 })
             }
             __syncthreads();
-            if (tid < 64) {
-                unsigned long long above;
-                int bkt = scan_hist<false>(hist, need, 0.f, &above);
-                if (tid == 0) { sh_i[0] = bkt; sh_u64[0] = above; }
-            }
-            __syncthreads();
-            prefix |= (uint32_t)sh_i[0] << (8 * pass);
+            unsigned long long above;
+            const int bkt = scan_hist<false>(hist, need, 0.f, &above);
+            prefix |= (uint32_t)bkt << (8 * pass);
             mask |= 0xffu << (8 * pass);
-            need -= sh_u64[0];
-            __syncthreads();
+            need -= above;
         }
         thr_key = prefix;
+        // `need` is now the rank of the k-th entry inside the last bucket: top_k - need keys lie strictly above thr_key and the
+        // last histogram counts the keys equal to it
+        n_alive = (unsigned long long)a.top_k - need + hist_all[3][prefix & 255u];
     }
     if (thr_key <= NEG_INF_KEY) thr_key = NEG_INF_KEY + 1;  // -inf entries are never alive
+
+    float best = -INFINITY;
+    int besti = 0;
+    if (EPT > 0 && n_alive <= (unsigned long long)SAMP_THREADS) {
+        // ------------------------------------------------------------------------------------------------ compacted tail
+        // At most one survivor per thread (any order: every reduction below is an integer sum, a histogram or a max with an index
+        // tie-break); the arithmetic per element is the one of the sweeps in the general tail below.
+        WMAR_FOR_ROW({
+            if (wmar_f32_key(xv) >= thr_key) { const int s_ = atomicAdd(&surv_n, 1); surv_x[s_] = xv; surv_v[s_] = (int)v; }
+        })
+        __syncthreads();
+        const bool my = tid < surv_n;
+        const float cx = my ? surv_x[tid] : 0.f;
+        const long long cv = my ? (long long)surv_v[tid] : 0;
+        const uint32_t ck = wmar_f32_key(cx);
+        const float ce = wmar_expf(cx - m);
+        uint32_t bkey = 0;
+        long long bidx = 0;
+        if (a.use_top_p) {
+            const unsigned long long S = block_sum_u64(my ? wmar_fx(ce) : 0ull, red_all[1]);
+            const float Sf = wmar_fx_to_f32(S);
+            const unsigned long long mass = my ? wmar_fx(ce / Sf) : 0ull;
+            const float thr = a.top_p_thr;
+            uint32_t prefix = 0, mask = 0;
+            unsigned long long base = 0;
+            bool all_pass = false;
+            for (int pass = 3; pass >= 0; --pass) {
+                unsigned long long* hist = hist_all[4 + 3 - pass];
+                if (my && (ck & mask) == prefix) atomicAdd(&hist[(ck >> (8 * pass)) & 255u], mass);
+                __syncthreads();
+                unsigned long long below;
+                const int bkt = scan_hist<true>(hist, base, thr, &below);
+                if (bkt < 0) { all_pass = true; break; }
+                prefix |= (uint32_t)bkt << (8 * pass);
+                mask |= 0xffu << (8 * pass);
+                base += below;
+            }
+            if (!all_pass) {
+                bkey = prefix;
+                const unsigned long long cnt = block_sum_u64((my && ck == bkey) ? 1ull : 0ull, red_all[2]);
+                if (cnt > 1) {
+                    uint32_t ipre = 0, imask = 0;
+                    for (int pass = 3; pass >= 0; --pass) {
+                        unsigned long long* hist = hist_all[8 + 3 - pass];
+                        if (my && ck == bkey && (((uint32_t)cv) & imask) == ipre)
+                            atomicAdd(&hist[(((uint32_t)cv) >> (8 * pass)) & 255u], mass);
+                        __syncthreads();
+                        unsigned long long below;
+                        const int bkt = scan_hist<true>(hist, base, thr, &below);
+                        ipre |= (uint32_t)(bkt < 0 ? 255 : bkt) << (8 * pass);
+                        imask |= 0xffu << (8 * pass);
+                        base += below;
+                    }
+                    bidx = (long long)ipre;
+                }
+            } else {
+                bkey = kmax;
+                bidx = (long long)block_max_u32((my && ck == kmax) ? (uint32_t)cv : 0u, red_all[3]);
+            }
+        }
+        const bool kept = my && (ck > bkey || (ck == bkey && cv >= bidx));
+        const unsigned long long S2 = block_sum_u64(kept ? wmar_fx(ce) : 0ull, red_all[4]);
+        const float Sf2 = wmar_fx_to_f32(S2);
+        if (kept) {
+            // (entries outside the kept set race with p = 0 in the general tail and never win: the row maximum is kept and its
+            // ratio is positive)
+            const float qv = (EPT <= 16) ? q_lds[cv] : q[WMAR_SRC(cv)];
+            best = (ce / Sf2) / qv;
+            besti = (int)cv;
+        }
+    } else {
+    // ---------------------------------------------------------------------------------------------------- general tail
 
     // top-p: boundary (K*, i*) of the ascending (value, index) order by mass-radix descent
     uint32_t bkey = 0;       // kept  <=>  key >= thr_key && (key > bkey || (key == bkey && idx >= bidx))
@@ -337,30 +420,22 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
         WMAR_FOR_ROW({
             if (wmar_f32_key(xv) >= thr_key) S += wmar_fx(wmar_expf(xv - m));
         })
-        S = block_sum_u64(S, red);
+        S = block_sum_u64(S, red_all[1]);
         const float Sf = wmar_fx_to_f32(S);
         const float thr = a.top_p_thr;
         uint32_t prefix = 0, mask = 0;
         unsigned long long base = 0;
         bool all_pass = false;
         for (int pass = 3; pass >= 0 && !all_pass; --pass) {
-            for (int i = tid; i < 256; i += SAMP_THREADS) hist[i] = 0;
-            __syncthreads();
+            unsigned long long* hist = hist_all[4 + 3 - pass];
             WMAR_FOR_ROW({
                 const uint32_t k = wmar_f32_key(xv);
                 if (k >= thr_key && (k & mask) == prefix)
                     atomicAdd(&hist[(k >> (8 * pass)) & 255u], wmar_fx(wmar_expf(xv - m) / Sf));
             })
             __syncthreads();
-            if (tid < 64) {
-                unsigned long long below;
-                int bkt = scan_hist<true>(hist, base, thr, &below);
-                if (tid == 0) { sh_i[0] = bkt; sh_u64[0] = below; }
-            }
-            __syncthreads();
-            int bkt = sh_i[0];
-            unsigned long long below = sh_u64[0];
-            __syncthreads();
+            unsigned long long below;
+            const int bkt = scan_hist<true>(hist, base, thr, &below);
             if (bkt < 0) { all_pass = true; break; }
             prefix |= (uint32_t)bkt << (8 * pass);
             mask |= 0xffu << (8 * pass);
@@ -371,26 +446,18 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
             bkey = prefix;
             unsigned long long cnt = 0;
             WMAR_FOR_ROW({ cnt += (wmar_f32_key(xv) == bkey); })
-            cnt = block_sum_u64(cnt, red);
+            cnt = block_sum_u64(cnt, red_all[2]);
             if (cnt > 1) {
                 uint32_t ipre = 0, imask = 0;
                 for (int pass = 3; pass >= 0; --pass) {
-                    for (int i = tid; i < 256; i += SAMP_THREADS) hist[i] = 0;
-                    __syncthreads();
+                    unsigned long long* hist = hist_all[8 + 3 - pass];
                     WMAR_FOR_ROW({
                         if (wmar_f32_key(xv) == bkey && (((uint32_t)v) & imask) == ipre)
                             atomicAdd(&hist[(((uint32_t)v) >> (8 * pass)) & 255u], wmar_fx(wmar_expf(xv - m) / Sf));
                     })
                     __syncthreads();
-                    if (tid < 64) {
-                        unsigned long long below;
-                        int bkt = scan_hist<true>(hist, base, thr, &below);
-                        if (tid == 0) { sh_i[0] = bkt; sh_u64[0] = below; }
-                    }
-                    __syncthreads();
-                    int bkt = sh_i[0];
-                    unsigned long long below = sh_u64[0];
-                    __syncthreads();
+                    unsigned long long below;
+                    const int bkt = scan_hist<true>(hist, base, thr, &below);
                     // the boundary value's bucket failed as a whole, so some index bucket fails too
                     ipre |= (uint32_t)(bkt < 0 ? 255 : bkt) << (8 * pass);
                     imask |= 0xffu << (8 * pass);
@@ -403,7 +470,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
             bkey = kmax;
             uint32_t imax = 0;
             WMAR_FOR_ROW({ if (wmar_f32_key(xv) == kmax) imax = max(imax, (uint32_t)v); })
-            bidx = (long long)block_max_u32(imax, red);
+            bidx = (long long)block_max_u32(imax, red_all[3]);
         }
     }
 
@@ -414,10 +481,8 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
         const bool kept = k >= thr_key && (k > bkey || (k == bkey && v >= bidx));
         if (kept) S2 += wmar_fx(wmar_expf(xv - m));
     })
-    S2 = block_sum_u64(S2, red);
+    S2 = block_sum_u64(S2, red_all[4]);
     const float Sf2 = wmar_fx_to_f32(S2);
-    float best = -INFINITY;
-    int besti = 0;
     if (EPT > 0) {
         constexpr int CH = EPT > 16 ? 16 : (EPT > 0 ? EPT : 1);
 #pragma unroll
@@ -453,6 +518,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void k_sample_fused(SampArgs a) {
             if (r > best) { best = r; besti = (int)v; }
         }
     }
+    }       // general tail
 #undef WMAR_FOR_ROW
     for (int o = 32; o > 0; o >>= 1) {
         float ob = __shfl_xor(best, o);
