@@ -1,9 +1,12 @@
 """The fused output projection + residual fold + LN2 statistics launch (k_bx_xr: split-K reduction behind an XCD-local L2 barrier) against
 the two-launch path (k_bx + k_resid_stats) it replaces, at production width (1536 x 24 heads, 64 rows).
 
-Both paths fold the same slabs in the same order; they differ only in how the LayerNorm statistics are chunked (16 chunks of 96 columns
-against 12 of 128), i.e. in the last bits of an fp64 sum: logits agree to fp32 rounding and the sampled tokens are identical.  The engine's
-status entry point reports clean flags (no barrier timeout, no block on a foreign XCD)."""
+Both paths fold the same slabs in the same order.  With four waves x 6 steps in phase 1 (WMAR_XR_NW4=1: the arithmetic of k_bx) they
+differ only in how the LayerNorm statistics are chunked (16 chunks of 96 columns against 12 of 128), i.e. in the last bits of an fp64 sum:
+logits agree to 2e-5 and the sampled tokens are identical.  The shipped launch splits a K slice over EIGHT waves x 3 steps (round 5): a
+different association of the same fp32 partial sums -- logits agree to 1e-4 (the depth tests' measure of fp32 rounding noise; logit scale
+10 here) and the sampled tokens can differ only where a race is closer than that (rows are independent: at most 2 of 64 rows may leave the
+other path's sequence).  The engine's status entry point reports clean flags (no barrier timeout, no block on a foreign XCD)."""
 import os
 import subprocess
 import sys
@@ -50,8 +53,15 @@ def test_fused_projection_matches_the_two_launch_path(tmp_path):
     # gfx950 in SPX mode: the probe must enable the fused launch -- a regression that silently keeps the two-launch path fails here
     assert "k_bx_xr" in plan_f, "the block -> XCD grouping probe did not enable the fused launch on this device: " + plan_f
     d = np.abs(fused["logits"] - plain["logits"]).max()
-    assert d <= 2e-5, d
-    assert np.array_equal(fused["tokens"], plain["tokens"])
+    assert d <= 1e-4, d
+    rows_off = int((fused["tokens"] != plain["tokens"]).any(axis=1).sum())
+    assert rows_off <= 2, rows_off
+    # the four-wave variant of the fused launch has k_bx's arithmetic: the round-4 bound holds for it
+    fused4, plan_4 = _run(tmp_path, "fused4", {"WMAR_XR_NW4": "1"})
+    assert "k_bx_xr" in plan_4
+    d4 = np.abs(fused4["logits"] - plain["logits"]).max()
+    assert d4 <= 2e-5, d4
+    assert np.array_equal(fused4["tokens"], plain["tokens"])
 
 
 def test_status_entry_point_and_phase_reset():

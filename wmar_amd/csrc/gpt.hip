@@ -878,6 +878,9 @@ int wmar_gpt_get_timing(wmar_gpt* g, double* total_us, int64_t* calls, double* s
     return WMAR_OK;
 }
 
+#ifndef WMAR_GRAPH_STEPS_DEFAULT
+#define WMAR_GRAPH_STEPS_DEFAULT 4       // 2 / 4 / 8 / 16 measured alike (3.723 -> 3.712 ms per step: the seam between two replays is ~10 us)
+#endif
 static int gpt_generate_once(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_sample_params* sp, const int64_t* cond_dev,
                              int64_t B, int32_t steps, const float* q_dev, int64_t* tokens_out_dev,
                              float* logits_trace_dev, void* stream) {
@@ -943,9 +946,20 @@ static int gpt_generate_once(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_samp
                                       0ull, 0ull, (unsigned long long)sp->top_k, 0ull};
         float fd = wm ? wm->delta : 0.f, ft = sp->temperature;
         memcpy(&key[8], &fd, 4); memcpy(&key[9], &ft, 4); memcpy(&key[11], &sp->top_p, 8);
-        if (memcmp(key, g->graph_key, sizeof(key)) != 0) g->drop_graph();
         bool need[wmar_gpt::N_PHASE] = {false, false, false};
         for (int n = 0; n < steps; ++n) need[g->att_phase(n + 1, B)] = true;
+        // Steps per captured graph: a run that stays in ONE attention phase (the default schedule) replays groups of `gs` steps, so
+        // the seam between two graph launches is paid once per group.
+        int gs = 1;
+        {
+            static int env_gs = -1;
+            if (env_gs < 0) { const char* e = getenv("WMAR_GRAPH_STEPS"); env_gs = e ? atoi(e) : 0; }
+            const int want = env_gs > 0 ? env_gs : WMAR_GRAPH_STEPS_DEFAULT;
+            const int n_need = (int)need[0] + (int)need[1] + (int)need[2];
+            if (n_need == 1 && want > 1 && steps % want == 0) gs = want;
+        }
+        key[1] |= (unsigned long long)gs << 32;
+        if (memcmp(key, g->graph_key, sizeof(key)) != 0) g->drop_graph();
         bool have = true;
         for (int ph = 0; ph < wmar_gpt::N_PHASE; ++ph) have = have && (!need[ph] || g->exec[ph]);
         if (!have) {
@@ -953,7 +967,8 @@ static int gpt_generate_once(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_samp
             for (int ph = 0; ph < wmar_gpt::N_PHASE; ++ph) {
                 if (!need[ph]) continue;          // only the phases this run passes through are captured
                 WMAR_HIP_CHECK(hipStreamBeginCapture(g->cap_stream, hipStreamCaptureModeThreadLocal));
-                int rc = one_step(g->cap_stream, ph);
+                int rc = WMAR_OK;
+                for (int k = 0; k < gs && rc == WMAR_OK; ++k) rc = one_step(g->cap_stream, ph);
                 hipError_t e = hipStreamEndCapture(g->cap_stream, &g->graph[ph]);
                 if (rc) { g->drop_graph(); return rc; }
                 if (e != hipSuccess) { g->drop_graph(); set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return WMAR_EHIP; }
@@ -963,7 +978,7 @@ static int gpt_generate_once(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_samp
             memcpy(g->graph_key, key, sizeof(key));
         }
         hipError_t e = hipSuccess;
-        for (int n = 0; n < steps && e == hipSuccess; ++n) e = hipGraphLaunch(g->exec[g->att_phase(n + 1, B)], st);
+        for (int n = 0; n < steps && e == hipSuccess; n += gs) e = hipGraphLaunch(g->exec[g->att_phase(n + 1, B)], st);
         if (e == hipSuccess) e = hipEventRecord(g->ev1, st);   // also marks "replays finished" for drop_graph()
         if (e == hipSuccess) { g->pending = true; }
         if (e != hipSuccess) { set_error("graph replay failed: %s", hipGetErrorString(e)); return WMAR_EHIP; }

@@ -525,6 +525,74 @@ __global__ __launch_bounds__(COT * 64) void k_conv_bx(ConvArgs a) {
     }
 }
 
+// ---- 3 x 3, stride 1, at most 4 real output channels (the decoders' 128 -> 3 output conv at 256 x 256: 2.9 ms per 64 images on a
+// 32-wide MFMA tile, where 29 of 32 output columns are padding -- 10 TF/s).  Round 5: fp32 FMAs on the vector ALU, one output
+// pixel per lane, the weights of a round (wf[round][tap][32 channels][4 couts], k_pack_conv_few) through the scalar cache as
+// SGPR operands; the patch staging (GroupNorm + swish applied on the way into LDS) is k_conv's.  16 x 16 output pixels per
+// workgroup, 46 KB of LDS: three workgroups per CU cover each other's staging.
+__global__ void k_pack_conv_few(const float* __restrict__ W, float* __restrict__ wf, int Cout, int Cin, int Cin_s) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // over (Cin_s / 32) * 9 * 32 * 4
+    if (idx >= Cin_s * 9 * 4) return;
+    const int co = idx & 3, ch = (idx >> 2) & 31, r = idx >> 7;
+    const int tap = r % 9, c = (r / 9) * 32 + ch;
+    wf[idx] = (co < Cout && c < Cin) ? W[((long long)co * Cin + c) * 9 + tap] : 0.f;
+}
+
+constexpr int CF_T = 16, CF_PW = CF_T + 2;
+template <int NCO>
+__global__ __launch_bounds__(256) void k_conv_few(ConvArgs a, const float* __restrict__ wf) {
+    extern __shared__ __attribute__((aligned(16))) float patch[];  // [CF_PW * CF_PW][CONV_PSTRIDE]
+    int bid = blockIdx.x;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int b = bid / a.tiles_y;
+    const int px = threadIdx.x & (CF_T - 1), py = threadIdx.x >> 4;
+    const int iy0 = ty * CF_T - 1, ix0 = tx * CF_T - 1;
+    const float* inb = a.in + (long long)b * a.Hs * a.Ws * a.Cin;
+    float acc[NCO];
+#pragma unroll
+    for (int i = 0; i < NCO; ++i) acc[i] = 0.f;
+    for (int c0 = 0; c0 < a.Cin; c0 += CONV_CCH) {
+        __syncthreads();                                   // the previous round's reads are done
+        for (int e = threadIdx.x; e < CF_PW * CF_PW * 8; e += 256) {
+            const int pix = e >> 3, qq = e & 7;
+            const int yy = pix / CF_PW, xx = pix - yy * CF_PW;
+            const int y = iy0 + yy, x = ix0 + xx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y >= 0 && y < a.Hs && x >= 0 && x < a.Ws) {
+                v = *(const float4*)(inb + ((long long)y * a.Ws + x) * a.Cin + c0 + qq * 4);
+                if (a.gn_mr) v = conv_gn(a, v, b, c0 + qq * 4);
+            }
+            *(float4*)(patch + pix * CONV_PSTRIDE + qq * 4) = v;
+        }
+        __syncthreads();
+        const float* w = wf + (long long)(c0 / CONV_CCH) * (9 * CONV_CCH * 4);      // uniform: scalar loads
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            const float* p = patch + ((py + dy) * CF_PW + px + dx) * CONV_PSTRIDE;
+#pragma unroll
+            for (int q = 0; q < CONV_CCH / 4; ++q) {
+                const float4 xv = *(const float4*)(p + q * 4);
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float* wj = w + (tap * CONV_CCH + q * 4 + j) * 4;
+#pragma unroll
+                    for (int i = 0; i < NCO; ++i) acc[i] += xs[j] * wj[i];
+                }
+            }
+        }
+    }
+    const long long pix = ((long long)b * a.Ho + ty * CF_T + py) * a.Wo + tx * CF_T + px;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NCO; ++i) o[i] = acc[i] + a.bias[i];
+    float* dst = a.out + pix * a.Cout_s;
+    *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+    for (int c = 4; c < a.Cout_s; c += 4) *(float4*)(dst + c) = make_float4(0.f, 0.f, 0.f, 0.f);     // padding channels (zero weights, zero bias)
+}
+
 // ------------------------------------------------------------------------ GroupNorm
 // pass 1: per (image, pixel chunk) partial (sum, sumsq) of every group, fp64.
 struct GnArgs {
@@ -799,6 +867,117 @@ __global__ __launch_bounds__(256) void k_vq_argmin(VqArgs a) {
     }
 }
 
+// Round 5: the same search with 32 * PT pixels per workgroup (PT = 4: every 1-KiB codebook operand feeds 16 MFMAs instead of 8 and
+// the 16 MB codebook is streamed by half as many workgroups) and the CODES split over CS workgroups per pixel group, so that
+// (pixels / 128) * CS fills the chip; the partial winners meet in a packed (ordered distance, index) word with atomicMin --
+// order-independent, and the smaller index wins a tie exactly as in the sequential rule above.  The codebook operands run through a
+// two-stage register ring across tile boundaries (in k_vq_argmin every k-block waited for its own L2 / MALL round trip: 34 % of
+// the fp32-MFMA rate).  Same MFMA sequence per (pixel, code), so the distances -- and the codes -- are bit-identical.
+__device__ __forceinline__ unsigned long long vq_pack(float d, int n) {
+    d = d + 0.0f;                                          // -0 -> +0: equal distances must compare equal
+    uint32_t u = __float_as_uint(d);
+    u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;            // monotone in d
+    return ((unsigned long long)u << 32) | (uint32_t)n;
+}
+
+template <int PT>
+__global__ __launch_bounds__(256) void k_vq_argmin_split(VqArgs a, unsigned long long* __restrict__ best, int CS) {
+    extern __shared__ __attribute__((aligned(16))) float zs[];  // [32 * PT][E + 4]
+    __shared__ unsigned long long wbest[4][32 * PT];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = blockIdx.x / CS, cs = blockIdx.x - grp * CS;
+    const long long p0 = (long long)grp * 32 * PT;
+    const int ZS = a.E + 4;
+    for (int e = threadIdx.x; e < 32 * PT * (a.E >> 2); e += 256) {
+        const int r = e / (a.E >> 2), c = (e % (a.E >> 2)) * 4;
+        const float4 v = (p0 + r < a.P) ? *(const float4*)(a.z + (p0 + r) * a.E + c) : make_float4(0, 0, 0, 0);
+        *(float4*)(zs + r * ZS + c) = v;
+    }
+    __syncthreads();
+    const int j = lane & 31, half = lane >> 5;
+    const int KB = a.E >> 3, NT = a.n_embed >> 5;
+    const int tps = NT / CS;                              // host: NT % CS == 0, tps >= 4
+    float zn[PT];
+    unsigned long long bk[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) { zn[i] = (p0 + 32 * i + j < a.P) ? a.znorm[p0 + 32 * i + j] : 0.f; bk[i] = ~0ull; }
+    const float* zrow = zs + j * ZS + half * 4;
+    constexpr int U = 4;
+    const int nst = KB / U;                               // host: KB % (2 * U) == 0
+    float4 wA[U], wB[U];
+#define WMAR_VQ_LOAD(WB, NTI, SI)                                                                  \
+    {                                                                                               \
+        const float4* wt_ = a.ep + ((long long)(NTI) * KB + (SI) * U) * 64 + lane;                  \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) WB[u] = wt_[u * 64];                          \
+    }
+#define WMAR_VQ_MMA(WB, SI)                                                                        \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                \
+        float4 x[PT];                                                                               \
+        _Pragma("unroll") for (int i = 0; i < PT; ++i) x[i] = *(const float4*)(zrow + 32 * i * ZS + ((SI) * U + u) * 8); \
+        _Pragma("unroll") for (int i = 0; i < PT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WB[u].x, x[i].x, acc[i], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < PT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WB[u].y, x[i].y, acc[i], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < PT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WB[u].z, x[i].z, acc[i], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < PT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(WB[u].w, x[i].w, acc[i], 0, 0, 0); \
+    }
+    const int nt_first = cs * tps + w, nt_end = (cs + 1) * tps;
+    WMAR_VQ_LOAD(wA, nt_first, 0)
+    for (int nt = nt_first; nt < nt_end; nt += 4) {
+        const bool last_tile = nt + 4 >= nt_end;
+        float4 en[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) en[g] = *(const float4*)(a.enorm + nt * 32 + 8 * g + 4 * half);
+        f32x16 acc[PT];
+#pragma unroll
+        for (int i = 0; i < PT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int st = 0; st < nst; st += 2) {
+            WMAR_VQ_LOAD(wB, nt, st + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            WMAR_VQ_MMA(wA, st)
+            __builtin_amdgcn_sched_barrier(0);
+            // the stage after next: the same tile, or the first stage of this wave's next tile (the very last request re-reads a
+            // valid block: no load sits under a branch)
+            const bool wrap = st + 2 >= nst;
+            WMAR_VQ_LOAD(wA, wrap ? (last_tile ? nt : nt + 4) : nt, wrap ? 0 : st + 2)
+            __builtin_amdgcn_sched_barrier(0);
+            WMAR_VQ_MMA(wB, st + 1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // lane holds pixel j of each tile and codes nt*32 + (r&3) + 8*(r>>2) + 4*half
+#pragma unroll
+        for (int i = 0; i < PT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float e_ = (r & 3) == 0 ? en[r >> 2].x : ((r & 3) == 1 ? en[r >> 2].y : ((r & 3) == 2 ? en[r >> 2].z : en[r >> 2].w));
+                const float d = (zn[i] + e_) - 2.0f * acc[i][r];
+                const unsigned long long k = vq_pack(d, n);
+                bk[i] = k < bk[i] ? k : bk[i];
+            }
+    }
+#undef WMAR_VQ_LOAD
+#undef WMAR_VQ_MMA
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const unsigned long long o = __shfl_xor(bk[i], 32);
+        bk[i] = o < bk[i] ? o : bk[i];
+        if (half == 0) wbest[w][i * 32 + j] = bk[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 * PT) {
+        unsigned long long v = wbest[0][threadIdx.x];
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) { const unsigned long long o = wbest[ww][threadIdx.x]; v = o < v ? o : v; }
+        if (p0 + threadIdx.x < a.P) atomicMin(best + p0 + threadIdx.x, v);
+    }
+}
+
+__global__ void k_vq_finish(const unsigned long long* __restrict__ best, long long* __restrict__ codes, long long P) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < P) codes[p] = (long long)(best[p] & 0xffffffffull);
+}
+
 // ------------------------------------------------------------------------ layout conversions
 // NCHW image -> NHWC with channels padded to Cs
 __global__ void k_nchw_to_nhwc(const float* __restrict__ src, float* __restrict__ dst, int C, int HW, int Cs) {
@@ -828,6 +1007,7 @@ using namespace wmar;
 struct ConvW {
     float4* wp = nullptr;
     u32x4* wq = nullptr;     // bf16 pieces for k_conv_bx (input channels a multiple of 32)
+    float* wf = nullptr;     // k_conv_few: 3 x 3 convs with at most 4 output channels
     float* bias = nullptr;
     int cin = 0, cout = 0, cin_s = 0, cout_s = 0, ks = 1, CT = 0, KBc = 0;
 };
@@ -865,6 +1045,7 @@ struct wmar_vq {
     double* gn_partial = nullptr;
     double* gn_tiles = nullptr; long long gn_tiles_cap = 0;   // per-tile GroupNorm partial sums written by conv epilogues
     float* znorm = nullptr;
+    unsigned long long* vqbest = nullptr;      // packed (distance, code) winners of k_vq_argmin_split
 
     template <typename T>
     int alloc(T** p, size_t n) {
@@ -938,6 +1119,12 @@ struct Loader {
             if ((rc = v->alloc(&c.wq, nq * 3))) return;
             hipLaunchKernelGGL(k_pack_conv_bx, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, W, c.wq, cout, cin, ks, c.CT, c.cin_s / 16);
             rc = launch_status("k_pack_conv_bx");
+        }
+        if (rc == WMAR_OK && c.cin_s % CONV_CCH == 0 && ks == 3 && cout <= 4) {
+            const size_t nf = (size_t)c.cin_s * 9 * 4;
+            if ((rc = v->alloc(&c.wf, nf))) return;
+            hipLaunchKernelGGL(k_pack_conv_few, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, W, c.wf, cout, cin, c.cin_s);
+            rc = launch_status("k_pack_conv_few");
         }
     }
     void norm(const std::string& p, int C, NormW& n) {
@@ -1034,7 +1221,16 @@ int run_conv(const ConvW& c, const float* in, float* out, const float* res, int 
     const unsigned grid = (unsigned)((long long)B * cgroups * (wide ? a.tiles_x / 2 : a.tiles_x) * a.tiles_y);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (vq_trace()) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
-    if (bx2) {
+    static const bool few_off = getenv("WMAR_CONV_FEW_OFF") != nullptr;      // A/B: keep the MFMA tile for the output conv
+    const bool few = c.wf && c.ks == 3 && stride == 1 && !up && !res && !stats && wq_bstride == 0 && c.cout <= 4 && a.Ho % CF_T == 0 &&
+                     a.Wo % CF_T == 0 && !few_off;
+    if (few) {
+        a.tiles_x = a.Wo / CF_T; a.tiles_y = a.Ho / CF_T;
+        const unsigned gridf = (unsigned)((long long)B * a.tiles_x * a.tiles_y);
+        const size_t ldsf = (size_t)CF_PW * CF_PW * CONV_PSTRIDE * sizeof(float);
+        if (c.cout == 3) hipLaunchKernelGGL(k_conv_few<3>, dim3(gridf), dim3(256), ldsf, st, a, (const float*)c.wf);
+        else hipLaunchKernelGGL(k_conv_few<4>, dim3(gridf), dim3(256), ldsf, st, a, (const float*)c.wf);
+    } else if (bx2) {
         static const hipError_t lds2_ok = hipFuncSetAttribute((const void*)k_conv_bx<4, 3, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         WMAR_REQUIRE(lds2_ok == hipSuccess, "k_conv_bx (stride 2): raising the dynamic LDS limit failed: %s", hipGetErrorString(lds2_ok));
         hipLaunchKernelGGL((k_conv_bx<4, 3, 2, 2>), dim3(grid), dim3(256), lds, st, a);
@@ -1062,6 +1258,28 @@ int run_conv(const ConvW& c, const float* in, float* out, const float* res, int 
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
     return launch_status("k_conv");
+}
+
+// nearest-code search: k_vq_argmin_split when the shape allows it (>= 128 pixels, 8 | E / 8, z tile within the LDS), else k_vq_argmin
+int run_vq_argmin(VqArgs a, unsigned long long* best, hipStream_t st) {
+    static const bool split_off = getenv("WMAR_VQ_NO_SPLIT") != nullptr;      // A/B
+    const int KB = a.E >> 3, NT = a.n_embed >> 5;
+    const size_t lds4 = (size_t)128 * (a.E + 4) * sizeof(float);
+    if (!split_off && best && a.P >= 128 && KB % 8 == 0 && NT >= 4 && lds4 <= 150 * 1024) {
+        const long long groups = (a.P + 127) / 128;
+        int CS = 1;                                        // code splits: fill 256 CUs, every wave keeps at least one 32-code tile
+        while (groups * CS * 2 <= 256 && NT % (CS * 2) == 0 && NT / (CS * 2) >= 4) CS *= 2;
+        WMAR_HIP_CHECK(hipMemsetAsync(best, 0xff, (size_t)a.P * 8, st));
+        static const hipError_t lds_ok = hipFuncSetAttribute((const void*)k_vq_argmin_split<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);      // + 4 KB static
+        WMAR_REQUIRE(lds_ok == hipSuccess, "k_vq_argmin_split: raising the dynamic LDS limit failed: %s", hipGetErrorString(lds_ok));
+        hipLaunchKernelGGL(k_vq_argmin_split<4>, dim3((unsigned)(groups * CS)), dim3(256), lds4, st, a, best, CS);
+        hipLaunchKernelGGL(k_vq_finish, dim3((unsigned)((a.P + 255) / 256)), dim3(256), 0, st, (const unsigned long long*)best, a.codes, a.P);
+        return launch_status("k_vq_argmin_split");
+    }
+    const size_t lds = (size_t)64 * (a.E + 4) * sizeof(float);
+    WMAR_HIP_CHECK(hipFuncSetAttribute((const void*)k_vq_argmin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_vq_argmin, dim3((unsigned)((a.P + 63) / 64)), dim3(256), lds, st, a);
+    return launch_status("k_vq_argmin");
 }
 
 // statistics of GroupNorm(x); the (mean, rstd) table lives behind the partial sums in the same allocation
@@ -1293,6 +1511,7 @@ int wmar_vq_create(const wmar_vq_config* cfg, const char* const* names, const vo
     v->gn_tiles_cap = (long long)v->Bmax * (cfg->resolution / 8) * (cfg->resolution / 8) * 64;
     TRY(v->alloc(&v->gn_tiles, (size_t)v->gn_tiles_cap));
     TRY(v->alloc(&v->znorm, (size_t)v->Bmax * S * S));
+    TRY(v->alloc(&v->vqbest, (size_t)v->Bmax * S * S));
     if (rc == WMAR_OK && hipStreamSynchronize(st) != hipSuccess) { set_error("vq_create: sync failed"); rc = WMAR_EHIP; }
 #undef TRY
     if (rc != WMAR_OK) { delete v; return rc; }
@@ -1390,10 +1609,7 @@ int wmar_vq_encode(wmar_vq* v, const float* images_dev, int64_t B, int64_t* code
     VqArgs a{};
     a.z = zq; a.ep = v->emb_p; a.enorm = v->enorm; a.znorm = v->znorm; a.codes = (long long*)codes_dev; a.P = P;
     a.E = E; a.n_embed = c.n_embed;
-    const size_t lds = (size_t)64 * (E + 4) * sizeof(float);
-    WMAR_HIP_CHECK(hipFuncSetAttribute((const void*)k_vq_argmin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_vq_argmin, dim3((unsigned)((P + 63) / 64)), dim3(256), lds, st, a);
-    return launch_status("k_vq_argmin");
+    return run_vq_argmin(a, v->vqbest, st);
 }
 
 }  // extern "C"
@@ -1464,6 +1680,7 @@ struct wmar_mvq {
     double* gn_partial = nullptr;
     double* gn_tiles = nullptr; long long gn_tiles_cap = 0;   // per-tile GroupNorm partial sums written by conv epilogues
     float* znorm = nullptr;
+    unsigned long long* vqbest = nullptr;      // packed (distance, code) winners of k_vq_argmin_split
     ~wmar_mvq() { for (void* p : allocs) (void)hipFree(p); }
 };
 
@@ -1585,6 +1802,7 @@ int wmar_mvq_create(const wmar_mvq_config* cfg, const char* const* names, const 
     v->gn_tiles_cap = (long long)v->Bmax * (cfg->resolution / 8) * (cfg->resolution / 8) * 64;
     TRY(arena.alloc(&v->gn_tiles, (size_t)v->gn_tiles_cap));
     TRY(arena.alloc(&v->znorm, (size_t)v->Bmax * S * S));
+    TRY(arena.alloc(&v->vqbest, (size_t)v->Bmax * S * S));
     if (rc == WMAR_OK && hipStreamSynchronize(st) != hipSuccess) { set_error("mvq_create: sync failed"); rc = WMAR_EHIP; }
 #undef TRY
     if (rc != WMAR_OK) { delete v; return rc; }
@@ -1675,10 +1893,7 @@ int wmar_mvq_encode(wmar_mvq* v, const float* images_dev, int64_t B, int64_t* co
     VqArgs a{};
     a.z = zq; a.ep = v->emb_p; a.enorm = v->enorm; a.znorm = v->znorm; a.codes = (long long*)codes_dev; a.P = P;
     a.E = z; a.n_embed = c.num_embeddings;
-    const size_t lds = (size_t)64 * (z + 4) * sizeof(float);
-    WMAR_HIP_CHECK(hipFuncSetAttribute((const void*)k_vq_argmin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_vq_argmin, dim3((unsigned)((P + 63) / 64)), dim3(256), lds, st, a);
-    return launch_status("k_vq_argmin");
+    return run_vq_argmin(a, v->vqbest, st);
 }
 
 }  // extern "C"
