@@ -444,13 +444,19 @@ int wmar_cham_generate_image(wmar_cham* g, const wmar_wm_ctx* wm, const int64_t*
     if (rc == WMAR_OK) rc = sample(st);                 // first image token from the prefill logits
     if (rc == WMAR_OK && n_tokens > 1) {
         if (sp->use_graph) {
-            e = hipStreamBeginCapture(g->cap_stream, hipStreamCaptureModeThreadLocal);
-            if (e == hipSuccess) {
-                rc = one_step(g->cap_stream);
-                e = hipStreamEndCapture(g->cap_stream, &g->graph);
+            // groups of four steps per captured graph (the seam between two replays is ~10 us, gpt.hip); the steps that do not
+            // fill a group are enqueued directly in front of the replays
+            const int gs = 4, lead = (n_tokens - 1) % gs;
+            for (int n = 0; n < lead && rc == WMAR_OK; ++n) rc = one_step(st);
+            if (rc == WMAR_OK && n_tokens - 1 - lead > 0) {
+                e = hipStreamBeginCapture(g->cap_stream, hipStreamCaptureModeThreadLocal);
+                if (e == hipSuccess) {
+                    for (int k = 0; k < gs && rc == WMAR_OK; ++k) rc = one_step(g->cap_stream);
+                    e = hipStreamEndCapture(g->cap_stream, &g->graph);
+                }
+                if (rc == WMAR_OK && e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+                for (int n = 1 + lead; n < n_tokens && rc == WMAR_OK && e == hipSuccess; n += gs) e = hipGraphLaunch(g->exec, st);
             }
-            if (rc == WMAR_OK && e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
-            for (int n = 1; n < n_tokens && rc == WMAR_OK && e == hipSuccess; ++n) e = hipGraphLaunch(g->exec, st);
             if (rc == WMAR_OK && e != hipSuccess) { set_error("cham_generate_image graph: %s", hipGetErrorString(e)); rc = WMAR_EHIP; }
         } else {
             for (int n = 1; n < n_tokens && rc == WMAR_OK; ++n) rc = one_step(st);

@@ -988,13 +988,16 @@ static int rar_generate_once(wmar_rar* g, const wmar_wm_ctx* wm, const int64_t* 
     };
     if (use_graph) {
         WMAR_HIP_CHECK(hipStreamBeginCapture(g->cap_stream, hipStreamCaptureModeThreadLocal));
-        int rc = one_step(g->cap_stream);
+        // groups of four positions per captured graph (the seam between two replays is ~10 us, gpt.hip)
+        const int gs = (L % 4 == 0) ? 4 : 1;
+        int rc = WMAR_OK;
+        for (int k = 0; k < gs && rc == WMAR_OK; ++k) rc = one_step(g->cap_stream);
         hipError_t e = hipStreamEndCapture(g->cap_stream, &g->graph);
         if (rc) { g->drop_graph(); return rc; }
         if (e != hipSuccess) { g->drop_graph(); set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return WMAR_EHIP; }
         e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
         if (e != hipSuccess) { g->drop_graph(); set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return WMAR_EHIP; }
-        for (int n = 0; n < L && e == hipSuccess; ++n) e = hipGraphLaunch(g->exec, st);
+        for (int n = 0; n < L && e == hipSuccess; n += gs) e = hipGraphLaunch(g->exec, st);
         if (e == hipSuccess) e = hipEventRecord(g->ev, st);
         if (e != hipSuccess) { set_error("graph replay failed: %s", hipGetErrorString(e)); return WMAR_EHIP; }
         g->pending = true;
