@@ -171,7 +171,10 @@ struct ChamPlan {
         t.D = g->D; t.H = g->H; t.Hkv = g->Hkv; t.Tmax = g->T; t.MT = MT; t.scale = 1.0f / sqrtf((float)g->hd);
         t.rope = g->rope;
         const dim3 grid((unsigned)(M * g->H));
-        if (g->hd == 128) hipLaunchKernelGGL((k_cham_attn<128, 2>), grid, dim3(128), 0, st, t);
+        static const int att_nw = getenv("WMAR_CHAM_NWA") ? atoi(getenv("WMAR_CHAM_NWA")) : 2;     // dev A/B: waves per (sequence, head)
+        if (g->hd == 128 && att_nw == 1) hipLaunchKernelGGL((k_cham_attn<128, 1>), grid, dim3(64), 0, st, t);
+        else if (g->hd == 128 && att_nw == 4) hipLaunchKernelGGL((k_cham_attn<128, 4>), grid, dim3(256), 0, st, t);
+        else if (g->hd == 128) hipLaunchKernelGGL((k_cham_attn<128, 2>), grid, dim3(128), 0, st, t);
         else hipLaunchKernelGGL((k_cham_attn<64, 2>), grid, dim3(128), 0, st, t);
         if ((rc = launch_status("k_cham_attn"))) return rc;
         BGemmArgs o = base();
