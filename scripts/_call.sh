@@ -1,3 +1,2 @@
 mkdir -p gpurun_out
-for nw in 2 1 4 2 1; do echo "NWA=$nw"; WMAR_CHAM_NWA=$nw timeout 600 python scripts/perf_cham.py 16 1024 0 2>&1 | grep "rep1"; done > gpurun_out/c10.log 2>&1
-cat gpurun_out/c10.log
+timeout 900 python -m pytest tests/test_gpu_vq_paths.py -m gpu -x -q 2>&1 | tail -15 > gpurun_out/c11.log; cat gpurun_out/c11.log
