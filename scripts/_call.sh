@@ -1,10 +1,11 @@
 mkdir -p gpurun_out
-R=$GRAFT_REPO_ROOT
-cd /tmp && export TMPDIR=/tmp
-for s in 0 4; do
-  if [ $s = 0 ]; then unset WMAR_S_FC2; else export WMAR_S_FC2=$s; fi
-  WMAR_ROOT=$R/build_alt/dev timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/c13_$s -- python $R/scripts/perf_gpt.py 64 256 1 > $R/gpurun_out/c13_$s.log 2>&1
-  f=$(find $R/gpurun_out/c13_$s -name "*kernel_stats.csv" | head -1); cp $f $R/gpurun_out/c13_${s}_kernel_stats.csv; rm -rf $R/gpurun_out/c13_$s
-done
-cd $R
-for s in 0 4; do echo "== S_FC2=$s"; grep -v "^W2026\|^E2026" gpurun_out/c13_$s.log | tail -3; head -8 gpurun_out/c13_${s}_kernel_stats.csv | cut -c1-120; done
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -4 > gpurun_out/c15_tests.log
+bash scripts/final_prof.sh r05f > gpurun_out/c15.log 2>&1
+cat gpurun_out/c15_tests.log
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r05f_bench_line.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['decode_step'], d['stage_seconds_per_batch'], d['roofline']['frac'], d['roofline']['avg_us'], d['roofline']['traffic'])
+for k,v in d['secondary'].items(): print(k, v['images_per_s'], v['ms_per_step'], v.get('vq_decode_s'), v.get('vq_encode_s'))
+print(d['cpu_baseline']['value'], d['cpu_baseline']['cores'])
+PY
