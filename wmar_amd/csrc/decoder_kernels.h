@@ -610,6 +610,7 @@ static __global__ void k_pack_fc1x(const float* __restrict__ W, const float* __r
 
 static __global__ __launch_bounds__(256) void k_fc1x(Fc1xArgs a) {
     __shared__ __attribute__((aligned(16))) float4 red[4][6][64];
+    __shared__ __attribute__((aligned(16))) double2 st_red[4][64];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tile = blockIdx.x;
@@ -694,8 +695,18 @@ static __global__ __launch_bounds__(256) void k_fc1x(Fc1xArgs a) {
     WMAR_FX_LOAD(xB, wqB, w8B, WMAR_FX_UNIT(1))
     WMAR_FX_LOAD(xC, wqC, w8C, WMAR_FX_UNIT(2))
     __builtin_amdgcn_sched_barrier(0);
-    float mu, rstd;       // LayerNorm statistics of row = lane, fetched behind the first operands
-    ln_row_stats(a.stats, a.n_chunks, 64, lane, a.K, &mu, &rstd);
+    // LayerNorm statistics of row = lane, fetched behind the first operands.  Round 5: wave w fetches chunks w, w + 4, ... only (four
+    // 1-KiB loads instead of sixteen per wave: 48 KiB less in the CU's first burst) and the four partial sums meet in LDS behind the
+    // K loop, in wave order.  (host: n_chunks <= 16)
+    double st_sm = 0, st_sq = 0;
+    {
+        double2 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = *(const double2*)(a.stats + ((long long)min(w + 4 * i, a.n_chunks - 1) * 64 + lane) * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (w + 4 * i < a.n_chunks) { st_sm += v[i].x; st_sq += v[i].y; }
+    }
     // the epilogue's column constants (folded-LN row sums, bias) of this wave's output groups gi = w and gi = w + 4 (waves 0, 1):
     // requested here (round 5) -- inside the epilogue they were a dependent L2 round trip per group with every store behind it
     // (in-loop stamps: 2.5 us from the last MFMA to the last store acknowledged)
@@ -750,7 +761,18 @@ static __global__ __launch_bounds__(256) void k_fc1x(Fc1xArgs a) {
         red[w][4][lane] = make_float4(v4[0][0], v4[0][1], v4[0][2], v4[0][3]);
         red[w][5][lane] = make_float4(v4[1][0], v4[1][1], v4[1][2], v4[1][3]);
     }
+    st_red[w][lane] = make_double2(st_sm, st_sq);
     __syncthreads();
+    float mu, rstd;
+    {
+        double sm = 0, sq = 0;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) { const double2 t = st_red[ww][lane]; sm += t.x; sq += t.y; }
+        const double invK = inv_count_f64((double)a.K);
+        const double mean = sm * invK;
+        mu = (float)mean;
+        rstd = rsqrtf((float)var_f64(sq * invK, mean) + 1e-5f);
+    }
     for (int gi = w; gi < 6; gi += 4) {
         float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -245,7 +245,7 @@ struct StepPlan {
     }
     // the predicates the launches below use (wmar_gpt_plan_info reports from the same ones)
     bool qkv_bx() const { return S_qx > 0 && MT == 2 && g->layers[0].wqkvx_bx && !g->no_bx && !g->no_bx_qkv; }
-    bool fc1_x() const { return MT == 2 && g->layers[0].wfc1x16; }
+    bool fc1_x() const { return MT == 2 && g->layers[0].wfc1x16 && nch_ln2 <= 16; }      // (k_fc1x: each wave fetches four of at most 16 statistics chunks)
     int qx_nkeep() const { const int G = 3 * D / 128; return G >= 4 && S_qx * 4 <= STAT_CHUNKS_MAX ? 4 : 1; }   // keeper groups per K slice (k_qkvx_bx)
     static bool head_narrow() { static int v = -1; if (v < 0) v = getenv("WMAR_HEAD_NARROW") ? 1 : 0; return v != 0; }   // A/B: the two-launch 32-column head
     int split_for(int NT, int KB) const { return pick_split(MT % 2 == 0 ? NT * (MT / 2) : NT * MT, KB, 4); }
