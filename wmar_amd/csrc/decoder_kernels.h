@@ -1350,6 +1350,8 @@ struct BxArgs {
     // GELU variant (S == 1): out is not written; gelu(sum + bias) goes out as bf16 pieces for the next k_bx GEMM
     const float* bias;         // [N]; without GELU: nullable, added to the slab (S == 1: finished values)
     u32x4* outq;               // planes [N/16][MTW][3][64]
+    int rowmajor;              // (NW == 4, no GELU) slab s as a ROW-MAJOR piece [32 MTW rows][N] instead of the packed layout: what the
+    int N;                     // attention prologue reads per (sequence, head) is then contiguous (k_qkvx_bx's epilogue, round 5)
 };
 
 #define WMAR_BX_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
@@ -1433,6 +1435,42 @@ __global__ __launch_bounds__(NW * 64) void k_bx(BxArgs a) {
     __syncthreads();
     // wave w sums rows w, w + 4, ... of the (tile, row tile, register group) rows over the four K quarters, in fixed order
     float4* out = a.out + (long long)ks * a.slab_stride;
+    if (!GELU && NW == 4 && a.rowmajor) {
+        // Row-major piece: with four waves, wave w holds register group g = w of every (tile, row tile) pair -- columns 8 w + 4 (lane / 32)
+        // .. + 3 of the 32-column tile, row lane % 32.  The pairs are turned through LDS (the reduction buffer, free behind a barrier):
+        // a store instruction then covers eight rows x 128 contiguous bytes.
+        constexpr int NP = NT * MTW, TS = 36;            // pairs; floats per row of a transposed tile (32 + 4: 16-byte rows on distinct banks)
+        static_assert(NP * 32 * TS * 4 <= (int)sizeof(red), "k_bx: transposed tiles do not fit the reduction buffer");
+        float4 vv[NP];
+#pragma unroll
+        for (int r = 0; r < NP; ++r) {
+            const int row = r * NW + w;
+            float4 v = red[0][row][lane];
+#pragma unroll
+            for (int o = 1; o < NW; ++o) { const float4 q = red[o][row][lane]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+            if (a.bias) {
+                const float4 bb = *(const float4*)(a.bias + ((grp * NT + r / MTW) * 4 + w) * 8 + 4 * (lane >> 5));
+                v = make_float4(v.x + bb.x, v.y + bb.y, v.z + bb.z, v.w + bb.w);
+            }
+            vv[r] = v;
+        }
+        __syncthreads();                                 // every wave has read its rows of `red`
+        float* T = reinterpret_cast<float*>(&red[0][0][0]);
+#pragma unroll
+        for (int r = 0; r < NP; ++r) *(float4*)(T + (r * 32 + (lane & 31)) * TS + 8 * w + 4 * (lane >> 5)) = vv[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = w; r < NP; r += NW) {
+            const int t = r / MTW, i = r % MTW;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = (lane >> 3) + 8 * it, cg = lane & 7;
+                const float4 v = *(const float4*)(T + (r * 32 + row) * TS + 4 * cg);
+                st_out(out + ((long long)(32 * i + row) * a.N + (grp * NT + t) * 32 + 4 * cg) / 4, v);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < (ROWS + NW - 1) / NW; ++r) {
         const int row = r * NW + w;

@@ -561,9 +561,15 @@ struct RarPlan {
         const long long o = (long long)l * 6 * D;   // chunk(6): shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
         int rc, S = 1;
         int S_qkv = 1;
+        bool qkv_rm = false;
         if (bx) {
             BxArgs x{};
             x.Wq = w.wqkv_bx; x.Xq = g->xq; x.out = g->qkv_slabs; x.slab_stride = 3 * act; x.KU = D / 16; x.S = g->bx_qkv.S;
+            // head_dim 80: the pieces go out row-major, so that the attention prologue of (row, head) reads 320 contiguous bytes per piece
+            // and q / k / v instead of 20 lines of the packed layout (k_attn_decode80 takes either; WMAR_RAR_QKV_PACKED=1: A/B)
+            static const bool qkv_packed = getenv("WMAR_RAR_QKV_PACKED") != nullptr;
+            qkv_rm = g->hd == 80 && att80() && !qkv_packed;
+            x.rowmajor = qkv_rm ? 1 : 0; x.N = 3 * D;
             if ((rc = launch_bx4<2>(x, 3 * D, g->bx_qkv.PER, st))) return rc;     // 64-column groups: half the activation reads per column
             S_qkv = g->bx_qkv.S;
         } else {
@@ -574,6 +580,7 @@ struct RarPlan {
         AttnArgs t{};
         const long long lstride = (long long)g->Mmax * g->H * g->T * g->hd;
         t.qkv_slabs = g->qkv_slabs; t.slab_stride = 3 * act; t.S = S_qkv; t.stats = g->stats; t.n_chunks = nch; t.K = D; t.invK = 1.0 / (double)D;
+        t.rowmajor = qkv_rm ? 1 : 0;
         t.bias = w.bqkv; t.mode = 1; t.qn_w = w.qnw; t.qn_b = w.qnb; t.kn_w = w.knw; t.kn_b = w.knb;
         t.kcache = g->kcache + l * lstride; t.vcache = g->vcache + l * lstride; t.y = g->y; t.yq = bx ? g->yq : nullptr; t.pos_dev = g->ctr;
         t.D = D; t.H = g->H; t.Tmax = g->T; t.MT = MT; t.scale = 1.0f / sqrtf((float)g->hd);
