@@ -1359,10 +1359,14 @@ struct BxArgs {
 // NW = waves per workgroup (4; 8 for RAR's FC1, round 5): the waves split the K slice, NW x PER x 16 k per workgroup.  A wave keeps one
 // step in flight beyond the one it computes, so a launch whose steps are bound by the latency of their loads takes PER x that latency:
 // twice the waves, half the steps.
-template <int NT, int PER, int MTW = 2, bool GELU = false, int NW = 4>
+// XF (round 5): the activation arrives as PACKED FP32 rows [K/8][MTW][64] instead of bf16 planes and is split in registers like the
+// weights -- 2 x 16 bytes per lane, row tile and step instead of 3 x 16 (a launch whose steps are bound by the bytes its CU pulls: RAR's
+// FC1, 983 KB of planes per workgroup); lane (row, k half) of the B operand fetches both halves of k-block 2 U + k half.  The pieces are
+// the ones bx_store_planes4 would have stored (same bx_split2 per pair): bit-identical results.
+template <int NT, int PER, int MTW = 2, bool GELU = false, int NW = 4, bool XF = false>
 __global__ __launch_bounds__(NW * 64) void k_bx(BxArgs a) {
     // MTW row tiles of 32 (2: 64 rows, 4: 128 rows -- RAR under guidance); planes [K/16][MTW][3][64], slabs packed [N/8][MTW][64]
-    constexpr int XR = 3 * MTW;             // 16-byte operand loads of a step
+    constexpr int XR = XF ? 2 * MTW : 3 * MTW;             // 16-byte operand loads of a step
     constexpr int ROWS = NT * 4 * MTW;      // float4 rows (tile, row tile, register group) of the workgroup's output
     __shared__ __attribute__((aligned(16))) float4 red[NW][ROWS][64];
     const int lane = threadIdx.x & 63;
@@ -1379,17 +1383,22 @@ __global__ __launch_bounds__(NW * 64) void k_bx(BxArgs a) {
             for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.f;
     const float4* wp = a.Wq + ((long long)grp * NT * a.KU + u0) * 128 + lane;
     const long long wt = (long long)a.KU * 128;     // next column tile
-    const u32x4* xp = a.Xq + (long long)u0 * XR * 64 + lane;
+    const u32x4* xp = XF ? a.Xq + ((long long)(2 * u0 + (lane >> 5)) * MTW) * 64 + (lane & 31)      // k-block 2 U + lane / 32, row lane % 32
+                         : a.Xq + (long long)u0 * XR * 64 + lane;
     float4 wr[NT][2];
-    u32x4 xr[XR];
+    u32x4 xr[XR], xr2[XF ? XR : 1];      // XF: the activation runs TWO steps ahead (even steps in xr, odd steps in xr2)
 #define WMAR_BX_LOADW(U)                                                                           \
     { _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                             \
         wr[t][0] = ld_nt(wp + t * wt + (long long)(U) * 128);                                      \
         wr[t][1] = ld_nt(wp + t * wt + (long long)(U) * 128 + 64); } }
+#define WMAR_BX_LOADXF(XB, U)                                                                      \
+    { _Pragma("unroll") for (int i = 0; i < MTW; ++i) {                                            \
+        XB[2 * i] = xp[((long long)(2 * (U)) * MTW + i) * 64];                                     \
+        XB[2 * i + 1] = xp[((long long)(2 * (U)) * MTW + i) * 64 + 32]; } }
 #define WMAR_BX_LOADX(U)                                                                           \
     { _Pragma("unroll") for (int q = 0; q < XR; ++q) xr[q] = xp[(long long)(U) * (XR * 64) + q * 64]; }
     WMAR_BX_LOADW(0);
-    WMAR_BX_LOADX(0);
+    if (XF) { WMAR_BX_LOADXF(xr, 0) if (1 < PER) WMAR_BX_LOADXF(xr2, 1) } else WMAR_BX_LOADX(0);
     __builtin_amdgcn_sched_barrier(0);
     bf16x8 ph[2][NT], pm[2][NT], pl[2][NT];
 #pragma unroll
@@ -1405,16 +1414,26 @@ __global__ __launch_bounds__(NW * 64) void k_bx(BxArgs a) {
             for (int t = 0; t < NT; ++t) bx_split8(wr[t][0], wr[t][1], ph[n][t], pm[n][t], pl[n][t]);
             if (j + 2 < PER) WMAR_BX_LOADW(j + 2);
         }
-        bf16x8 x[XR];
+        bf16x8 x[3 * MTW];
+        if (XF) {
 #pragma unroll
-        for (int q = 0; q < XR; ++q) x[q] = __builtin_bit_cast(bf16x8, xr[q]);
+            for (int i = 0; i < MTW; ++i) {
+                const u32x4 lo = c ? xr2[(2 * i) % (XF ? XR : 1)] : xr[2 * i], hi = c ? xr2[(2 * i + 1) % (XF ? XR : 1)] : xr[2 * i + 1];
+                bx_split8(__builtin_bit_cast(float4, lo), __builtin_bit_cast(float4, hi), x[3 * i], x[3 * i + 1], x[3 * i + 2]);
+            }
+            // the buffer just split is free: step j + 2 is requested before this step's MFMAs
+            if (j + 2 < PER) { if (c) WMAR_BX_LOADXF(xr2, j + 2) else WMAR_BX_LOADXF(xr, j + 2) }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 3 * MTW; ++q) x[q] = __builtin_bit_cast(bf16x8, xr[XF ? 0 : q]);
+        }
         // x[3 mt + piece]; the small products first
 #define WMAR_BX_ROUND(WP, XP)                                                                      \
         _Pragma("unroll") for (int t = 0; t < NT; ++t)                                             \
             _Pragma("unroll") for (int i = 0; i < MTW; ++i) WMAR_BX_MFMA(WP[c][t], x[3 * i + XP], acc[t][i]);
         WMAR_BX_ROUND(pl, 0) WMAR_BX_ROUND(ph, 2) WMAR_BX_ROUND(pm, 1) WMAR_BX_ROUND(pm, 0) WMAR_BX_ROUND(ph, 1) WMAR_BX_ROUND(ph, 0)
 #undef WMAR_BX_ROUND
-        if (j + 1 < PER) WMAR_BX_LOADX(j + 1);
+        if (!XF && j + 1 < PER) WMAR_BX_LOADX(j + 1);
 #pragma unroll
         for (int i = 0; i < 6 * MTW * NT; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1425,6 +1444,7 @@ __global__ __launch_bounds__(NW * 64) void k_bx(BxArgs a) {
     }
 #undef WMAR_BX_LOADW
 #undef WMAR_BX_LOADX
+#undef WMAR_BX_LOADXF
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -1497,9 +1517,9 @@ __global__ __launch_bounds__(NW * 64) void k_bx(BxArgs a) {
 constexpr int BX_PER = 6;              // 16-k steps per wave: K slice = 4 waves x 6 x 16 = 384
 constexpr int BX_KSLICE = 4 * BX_PER * 16;
 // N must be a multiple of 32 * NT, K = S * 64 * PER; 32 * MTW rows
-template <int NT, int PER = BX_PER, int MTW = 2, bool GELU = false, int NW = 4>
+template <int NT, int PER = BX_PER, int MTW = 2, bool GELU = false, int NW = 4, bool XF = false>
 static int launch_bx(const BxArgs& a, int N, hipStream_t st) {
-    hipLaunchKernelGGL((k_bx<NT, PER, MTW, GELU, NW>), dim3((unsigned)(N / (32 * NT) * a.S)), dim3(NW * 64), 0, st, a);
+    hipLaunchKernelGGL((k_bx<NT, PER, MTW, GELU, NW, XF>), dim3((unsigned)(N / (32 * NT) * a.S)), dim3(NW * 64), 0, st, a);
     return launch_status("k_bx");
 }
 

@@ -620,14 +620,18 @@ struct RarPlan {
             if ((rc = gemm_split(p, &S, st, S_proj))) return rc;
         }
         const bool fc1x = fc1_bx();
+        // round 5: eight waves x 10 steps instead of four x 20 (WMAR_RAR_FC1_NW4=1: the round-2 form, A/B); the operand as packed fp32
+        // rows split in registers instead of bf16 planes (two thirds of the activation bytes; WMAR_RAR_FC1_PLANES=1: A/B)
+        static const bool nw4 = getenv("WMAR_RAR_FC1_NW4") != nullptr;
+        static const bool fc1_planes = getenv("WMAR_RAR_FC1_PLANES") != nullptr;
+        const bool fc1_xf = fc1x && !nw4 && !fc1_planes;
         // x += gate_msa * (proj + bias);  norm2 + modulate(shift_mlp, scale_mlp) -> the FC1 operand
-        if ((rc = resid_mod(2 * l, w.bproj, S_proj, o + 2 * D, w.n2w, w.n2b, o + 3 * D, o + 4 * D, fc1x ? g->xq : nullptr))) return rc;
+        if ((rc = resid_mod(2 * l, w.bproj, S_proj, o + 2 * D, w.n2w, w.n2b, o + 3 * D, o + 4 * D, (fc1x && !fc1_xf) ? g->xq : nullptr))) return rc;
         if (fc1x) {
             BxArgs x{};
-            x.Wq = w.wfc1_bx; x.Xq = g->xq; x.KU = D / 16; x.S = 1; x.bias = w.bfc1; x.outq = g->hq;
-            // round 5: eight waves x 10 steps instead of four x 20 (WMAR_RAR_FC1_NW4=1: the round-2 form, A/B)
-            static const bool nw4 = getenv("WMAR_RAR_FC1_NW4") != nullptr;
+            x.Wq = w.wfc1_bx; x.Xq = fc1_xf ? (const u32x4*)g->h : g->xq; x.KU = D / 16; x.S = 1; x.bias = w.bfc1; x.outq = g->hq;
             if (nw4) { if ((rc = launch_bx<1, 20, 4, true>(x, g->F, st))) return rc; }
+            else if (fc1_xf) { if ((rc = launch_bx<1, 10, 4, true, 8, true>(x, g->F, st))) return rc; }
             else if ((rc = launch_bx<1, 10, 4, true, 8>(x, g->F, st))) return rc;
         } else {
             GemmArgs f = base();
