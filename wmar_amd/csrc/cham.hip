@@ -130,7 +130,7 @@ struct ChamPlan {
     long long act8;     // floats per fp32 piece of a D-wide output
     SkInfo sk_qkv, sk_o, sk_13, sk_2, sk_head;
     ChamPlan(wmar_cham* g_, int M_, hipStream_t st_) : g(g_), M(M_), st(st_) {
-        MT = g->MT; KBD = g->D / 16; KBF = g->F / 16; nch = (KBD + CHAM_STAT_KB - 1) / CHAM_STAT_KB;
+        MT = g->MT; KBD = g->D / 16; KBF = g->F / 16; nch = (KBD + CHAM_STAT_KB - 1) / CHAM_STAT_KB;      // (<= 128: checked at creation)
         act8 = (long long)g->D * MT * 32;
         sk_qkv = sk_for((g->D + 2 * g->Dkv) / 32, KBD, false);
         sk_o = sk_for(g->D / 32, KBD, false);
@@ -232,6 +232,7 @@ int wmar_cham_create(const wmar_cham_config* cfg, const char* const* names, cons
     WMAR_REQUIRE(!cfg->swin_norm, "cham_create: swin_norm (Chameleon-30B block order) is not supported");
     WMAR_REQUIRE(cfg->max_rows >= 1 && cfg->max_rows <= 128, "cham_create: max_rows must be in 1..128");
     WMAR_REQUIRE(cfg->max_seq_len >= 2, "cham_create: max_seq_len too small");
+    WMAR_REQUIRE((D / 16 + CHAM_STAT_KB - 1) / CHAM_STAT_KB <= 128, "cham_create: dim %d gives more than 128 statistics chunks (k_cham_attn reads two per lane)", D);
     TensorMap tm;
     for (int i = 0; i < n_tensors; ++i) tm.m[names[i]] = tensors_dev[i];
     hipStream_t st = (hipStream_t)stream;

@@ -356,8 +356,17 @@ static __global__ __launch_bounds__(256) void k_cham_swiglu(SwigluArgs a) {
     }
     {   // 1/rms of the 32 rows: 8 thread groups x (n_chunks / 8) statistics chunks each
         const int r = threadIdx.x & 31, grp = threadIdx.x >> 5;
+        // (round 5: the group's chunks are requested sixteen at a time with clamped indices -- a load inside a counted loop is one L2 round
+        // trip per chunk, 8 of them at 4096 features; same summation order)
         double ssum = 0;
-        for (int c = grp; c < a.n_chunks; c += 8) ssum += a.ssq[(long long)c * a.MT * 32 + mt * 32 + r];
+        for (int c0 = grp; c0 < a.n_chunks; c0 += 8 * 16) {
+            double v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = a.ssq[(long long)min(c0 + 8 * i, a.n_chunks - 1) * a.MT * 32 + mt * 32 + r];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (c0 + 8 * i < a.n_chunks) ssum += v[i];
+        }
         red[grp][r] = ssum;
     }
     __syncthreads();
@@ -526,8 +535,11 @@ __global__ __launch_bounds__(NWA * 64) void k_cham_attn(ChamAttnArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     if (w == 0) {
         // 1/rms of this row (one statistics chunk per lane), the q/k/v columns of this head from the slabs
-        double ssum = 0;
-        for (int c = lane; c < a.n_chunks; c += 64) ssum += a.ssq[(long long)c * a.MT * 32 + m];
+        // straight-line (host: n_chunks <= 128): a load inside a loop makes hipcc wait for EVERY outstanding load at its head, the first
+        // K / V chunk requested above included (k_attn_decode's prologue, decoder_kernels.h)
+        const double s0_ = a.ssq[(long long)min(lane, a.n_chunks - 1) * a.MT * 32 + m];
+        const double s1_ = a.ssq[(long long)min(lane + 64, a.n_chunks - 1) * a.MT * 32 + m];
+        double ssum = (lane < a.n_chunks ? s0_ : 0.0) + (lane + 64 < a.n_chunks ? s1_ : 0.0);
         float v3[3][8];
         float4 rp0 = make_float4(1.f, 0.f, 1.f, 0.f), rp1 = rp0;
         if (rsel == 0) {
