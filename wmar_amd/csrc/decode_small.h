@@ -1,0 +1,364 @@
+// Small-batch decode step (1..8 sequences) of the Taming minGPT engine: weight STREAMING kernels, no matrix cores.
+//
+// Reference: deps/taming/modules/transformer/mingpt.py:69-95 (attention), :112-122 (Block), :183-214 (forward_with_past) at the batch
+// sizes the reference itself runs (configs/taming_generate.json: batch 5; BASELINE configs[0]: batch 1).
+//
+// Why a second path.  At <= 8 rows a decode step is the 5.54 GB weight stream and nothing else (0.69 ms at 8 TB/s): every weight
+// feeds <= 8 multiply-adds, so a 32-row MFMA tile is 75-97 % padding and the fp32 matrix pipe itself becomes the bound (32x32x2:
+// 0.56 ms per step at peak), and the big-batch plan's split-K slabs + fold launches are pure fixed cost (round 5: 2.7 ms per step at
+// batch 5 = 0.25 of the stream).  Here a step is FIVE launches per layer and no partial sums ever leave a workgroup:
+//
+//   k_sgemv<QKV>   LayerNorm 1 + QKV projection + bias; k / v rows go straight into the cache, q into a [rows][D] buffer
+//   k_sattn        one workgroup per (sequence, head): softmax(q K^T / 8) V over the cached rows, four waves split the rows
+//   k_sgemv<PROJ>  x += y Wp^T + b            (residual stream updated in place: a workgroup owns its columns)
+//   k_sgemv<FC1>   LayerNorm 2 + FC1 + bias + exact-erf GELU
+//   k_sgemv<FC2>   x += h W2^T + b
+//
+// k_sgemv: the weights stay in the checkpoint's own row-major [N][K] layout; a wave-wide 16-byte load is 1 KiB = 256 consecutive k of
+// ONE output column, so a workgroup can own ANY number of columns and every launch is exactly 256 workgroups (18 / 6 / 24 / 6 / 64
+// columns for QKV / proj / FC1 / FC2 / head at n_embd 1536) with whole K inside the workgroup.  K is cut into segments of 768 (three
+// loads per lane); a wave owns one segment and a column range, keeps its slice of the <= 8 activation rows in REGISTERS (12 VGPRs per
+// row, LayerNorm applied once while they are loaded: every workgroup recomputes the row statistics from the 6 KB rows it reads
+// anyway), and turns every weight load into 4 x rows fused multiply-adds on the vector ALU (rows <= 8: <= 45 % of the VALU rate at
+// the HBM rate a CU can get).  Lane-partial dot products of a group of CG columns x rows meet in ONE transposing butterfly
+// (values halve while lane distance halves: ~CG x rows shuffles instead of 6 per value), the segments' partial sums meet in LDS in a
+// fixed order -- deterministic, no atomics.  Weight loads are non-temporal and double-buffered by column group; the first group is
+// requested before anything else in the kernel (the weights do not depend on the launch in front).
+#pragma once
+#include "decoder_kernels.h"
+
+namespace wmar {
+
+enum { SG_QKV = 0, SG_PROJ = 1, SG_FC1 = 2, SG_FC2 = 3, SG_HEAD = 4 };
+constexpr int SG_CH = 3;                 // 1-KiB loads per (column, segment): segment = 768 k
+constexpr int SG_SEG = SG_CH * 256;
+constexpr int SG_MAX_ROWS = 8;
+
+struct SgArgs {
+    const float* W;        // [N][K] row-major (the checkpoint's layout)
+    const float* bias;     // [N] or null
+    const float* x;        // [rows][K] row-major input rows
+    const float* gamma;    // [K] LayerNorm weight / bias in front of the Linear (QKV, FC1, head)
+    const float* beta;
+    float* out;            // PROJ / FC2: residual stream [rows][N], updated in place; FC1: hidden [rows][N]; HEAD: logits [rows][N]; QKV: q [rows][D]
+    float* kcache;         // QKV: this layer's [Bmax][H][Tmax][64]
+    float* vcache;
+    const int* pos_dev;
+    int N, K;
+    int D, H, Tmax;
+};
+
+// Sum of R per-lane values over the 64 lanes of a wave, all R at once: while the lane distance halves the value count halves (the
+// lane keeps one of a pair and sends the other), so the whole reduction is P - 1 + (6 - log2 P) shuffles for P = R rounded up to a
+// power of two, instead of 6 R.  On return v[0] of lane l is the total of value `idx`, idx = sum_j bit(l, 5 - j) << j over the
+// log2 P halving steps (lanes that differ only in the low bits hold copies).  Fixed order: the result is a function of the inputs only.
+template <int R, typename T>
+__device__ __forceinline__ T wave_reduce_many(T (&v)[R], int lane, int* idx_out) {
+    constexpr int P = R <= 1 ? 1 : R <= 2 ? 2 : R <= 4 ? 4 : R <= 8 ? 8 : R <= 16 ? 16 : R <= 32 ? 32 : 64;
+    static_assert(R <= 64, "at most 64 values per lane");
+    T t[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) t[i] = i < R ? v[i] : (T)0;
+    int idx = 0;
+    int cnt = P, off = 32, j = 0;
+#pragma unroll
+    for (int step = 0; step < 6; ++step) {
+        if (cnt > 1) {
+            const bool up = (lane & off) != 0;
+#pragma unroll
+            for (int i = 0; i < P / 2; ++i) {
+                if (i < cnt / 2) {
+                    const T keep = up ? t[2 * i + 1] : t[2 * i];
+                    const T send = up ? t[2 * i] : t[2 * i + 1];
+                    t[i] = keep + __shfl_xor(send, off);
+                }
+            }
+            idx |= (up ? 1 : 0) << j;
+            cnt /= 2; ++j;
+        } else {
+            t[0] += __shfl_xor(t[0], off);
+        }
+        off >>= 1;
+    }
+    *idx_out = idx;
+    return t[0];
+}
+template <int R> constexpr int sg_log2p() { return R <= 1 ? 0 : R <= 2 ? 1 : R <= 4 ? 2 : R <= 8 ? 3 : R <= 16 ? 4 : R <= 32 ? 5 : 6; }
+
+// grid = ceil(N / columns per workgroup); block = 256 (512 for FC2: eight K segments).  G column groups of CG columns per wave, at
+// compile time: the group loop is unrolled so that exactly the weights that are used are requested (a run-time trip count would need
+// either a branch around the prefetch -- hipcc then waits for BOTH buffers at the merge -- or clamped dummy loads, 2 x the bytes at G = 1).
+template <int NB, int CG, int G, int ROLE>
+__global__ __launch_bounds__(ROLE == SG_FC2 ? 512 : 256) void k_sgemv(SgArgs a) {
+    constexpr int CH = SG_CH;
+    constexpr bool LN = ROLE == SG_QKV || ROLE == SG_FC1 || ROLE == SG_HEAD;
+    constexpr int NW = ROLE == SG_FC2 ? 8 : 4;
+    constexpr int NSEG = ROLE == SG_FC2 ? 8 : 2;        // K = NSEG * 768
+    constexpr int NSPLIT = NW / NSEG;                     // waves that share a segment split the workgroup's columns
+    constexpr int R = CG * NB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sg_smem[];
+    double* lnred = (double*)sg_smem;                     // [NW][2 NB] (LN roles)
+    float* part = (float*)(sg_smem + NW * 2 * SG_MAX_ROWS * sizeof(double));   // [NSEG][cols_wg][NB]
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int seg = w / NSPLIT, chalf = w % NSPLIT;
+    constexpr int cols_wave = CG * G, cols_wg = NSPLIT * cols_wave;
+    const int n0 = blockIdx.x * cols_wg + chalf * cols_wave;
+    const long long K = a.K;
+    const float* wbase = a.W + (long long)seg * SG_SEG + lane * 4;
+
+    float4 wbuf[2][CG * CH];
+#define WMAR_SG_LOADW(BUF, GI)                                                                 \
+    {                                                                                          \
+        _Pragma("unroll") for (int c = 0; c < CG; ++c) {                                       \
+            int n_ = n0 + (GI) * CG + c;                                                       \
+            n_ = n_ < a.N ? n_ : a.N - 1;                                                      \
+            const float4* p_ = (const float4*)(wbase + (long long)n_ * K);                     \
+            _Pragma("unroll") for (int ch = 0; ch < CH; ++ch) BUF[c * CH + ch] = ld_nt(p_ + ch * 64); \
+        }                                                                                      \
+    }
+    WMAR_SG_LOADW(wbuf[0], 0)
+
+    // this wave's slice of the input rows (and of the LayerNorm parameters)
+    float4 xr[CH][NB];
+    {
+        const float* xb = a.x + (long long)seg * SG_SEG + lane * 4;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) xr[ch][b] = *((const float4*)(xb + (long long)b * K) + ch * 64);
+    }
+    if (LN) {
+        float4 gm[CH], bt[CH];
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+            gm[ch] = *((const float4*)(a.gamma + seg * SG_SEG + lane * 4) + ch * 64);
+            bt[ch] = *((const float4*)(a.beta + seg * SG_SEG + lane * 4) + ch * 64);
+        }
+        double st[2 * NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            double s = 0.0, ss = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) {
+                const float4 v = xr[ch][b];
+                s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+                ss += sq4_f64(v);
+            }
+            st[2 * b] = s; st[2 * b + 1] = ss;
+        }
+        int sidx;
+        const double tot = wave_reduce_many<2 * NB, double>(st, lane, &sidx);
+        constexpr int LB = sg_log2p<2 * NB>();
+        if ((lane & ((64 >> LB) - 1)) == 0 && sidx < 2 * NB) lnred[w * 2 * SG_MAX_ROWS + sidx] = tot;
+        __syncthreads();
+        const double invK = inv_count_f64((double)a.K);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            // segment 0 is wave 0, segment 1 is wave NSPLIT (LN roles have two segments)
+            const double sm = lnred[2 * b] + lnred[NSPLIT * 2 * SG_MAX_ROWS + 2 * b];
+            const double sq = lnred[2 * b + 1] + lnred[NSPLIT * 2 * SG_MAX_ROWS + 2 * b + 1];
+            const double mean = sm * invK;
+            const float mu = (float)mean;
+            const float rstd = rsqrtf((float)var_f64(sq * invK, mean) + 1e-5f);
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) {
+                float4 v = xr[ch][b];
+                v.x = (v.x - mu) * rstd * gm[ch].x + bt[ch].x;
+                v.y = (v.y - mu) * rstd * gm[ch].y + bt[ch].y;
+                v.z = (v.z - mu) * rstd * gm[ch].z + bt[ch].z;
+                v.w = (v.w - mu) * rstd * gm[ch].w + bt[ch].w;
+                xr[ch][b] = v;
+            }
+        }
+    }
+
+#define WMAR_SG_COMPUTE(BUF, GI)                                                               \
+    {                                                                                          \
+        float acc[R];                                                                          \
+        _Pragma("unroll") for (int i = 0; i < R; ++i) acc[i] = 0.f;                            \
+        _Pragma("unroll") for (int c = 0; c < CG; ++c)                                         \
+            _Pragma("unroll") for (int ch = 0; ch < CH; ++ch) {                                \
+                const float4 wv = BUF[c * CH + ch];                                            \
+                _Pragma("unroll") for (int b = 0; b < NB; ++b) {                               \
+                    float s_ = acc[c * NB + b];                                                \
+                    s_ = fmaf(wv.x, xr[ch][b].x, s_); s_ = fmaf(wv.y, xr[ch][b].y, s_);       \
+                    s_ = fmaf(wv.z, xr[ch][b].z, s_); s_ = fmaf(wv.w, xr[ch][b].w, s_);       \
+                    acc[c * NB + b] = s_;                                                      \
+                }                                                                              \
+            }                                                                                  \
+        int ridx;                                                                              \
+        const float tot_ = wave_reduce_many<R, float>(acc, lane, &ridx);                       \
+        constexpr int LBR = sg_log2p<R>();                                                     \
+        if ((lane & ((64 >> LBR) - 1)) == 0 && ridx < R) {                                     \
+            const int c_ = ridx / NB, b_ = ridx - c_ * NB;                                     \
+            part[((long long)seg * cols_wg + chalf * cols_wave + (GI) * CG + c_) * NB + b_] = tot_; \
+        }                                                                                      \
+    }
+
+    // column groups: the next group's weights are requested before the current group is used
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (g + 1 < G) WMAR_SG_LOADW(wbuf[(g + 1) & 1], g + 1)
+        WMAR_SG_COMPUTE(wbuf[g & 1], g)
+    }
+#undef WMAR_SG_LOADW
+#undef WMAR_SG_COMPUTE
+    __syncthreads();
+
+    // segment sums in a fixed order + epilogue; column fastest so that the stores of a row are contiguous
+    const int pos = (ROLE == SG_QKV) ? *a.pos_dev : 0;
+    for (int t = threadIdx.x; t < cols_wg * NB; t += NW * 64) {
+        const int b = t / cols_wg, col = t - b * cols_wg;
+        const int n = blockIdx.x * cols_wg + col;
+        if (n >= a.N) continue;
+        float s = part[(long long)col * NB + b];
+#pragma unroll
+        for (int sg = 1; sg < NSEG; ++sg) s += part[((long long)sg * cols_wg + col) * NB + b];
+        if (ROLE != SG_HEAD) s += a.bias[n];
+        if (ROLE == SG_QKV) {
+            const int which = n / a.D, j = n - which * a.D;
+            if (which == 0) a.out[(long long)b * a.D + j] = s;
+            else {
+                const int h = j >> 6, d = j & 63;
+                float* cache = which == 1 ? a.kcache : a.vcache;
+                cache[(((long long)b * a.H + h) * a.Tmax + pos) * 64 + d] = s;
+            }
+        } else if (ROLE == SG_PROJ || ROLE == SG_FC2) {
+            float* o = a.out + (long long)b * a.N + n;
+            *o = *o + s;
+        } else if (ROLE == SG_FC1) {
+            a.out[(long long)b * a.N + n] = gelu_erf(s);
+        } else {
+            a.out[(long long)b * a.N + n] = s;
+        }
+    }
+}
+
+template <int ROLE> constexpr int sg_nseg() { return ROLE == SG_FC2 ? 8 : 2; }
+template <int ROLE> constexpr int sg_nw() { return ROLE == SG_FC2 ? 8 : 4; }
+
+// columns per workgroup
+template <int CG, int G, int ROLE>
+constexpr int sg_cols_wg() { return (sg_nw<ROLE>() / sg_nseg<ROLE>()) * CG * G; }
+
+template <int NB, int CG, int G, int ROLE>
+static int launch_sgemv_nb(const SgArgs& a, hipStream_t st) {
+    constexpr int cols_wg = sg_cols_wg<CG, G, ROLE>();
+    const int grid = (a.N + cols_wg - 1) / cols_wg;
+    const size_t lds = (size_t)sg_nw<ROLE>() * 2 * SG_MAX_ROWS * sizeof(double) + (size_t)sg_nseg<ROLE>() * cols_wg * NB * sizeof(float);
+    hipLaunchKernelGGL((k_sgemv<NB, CG, G, ROLE>), dim3((unsigned)grid), dim3(sg_nw<ROLE>() * 64), lds, st, a);
+    return launch_status("k_sgemv");
+}
+
+template <int CG, int G, int ROLE>
+static int launch_sgemv(const SgArgs& a, int rows, hipStream_t st) {
+    if (a.K != sg_nseg<ROLE>() * SG_SEG) { set_error("k_sgemv: K = %d is not %d segments of %d", a.K, sg_nseg<ROLE>(), SG_SEG); return WMAR_EINVAL; }
+    switch (rows) {
+        case 1: return launch_sgemv_nb<1, CG, G, ROLE>(a, st);
+        case 2: return launch_sgemv_nb<2, CG, G, ROLE>(a, st);
+        case 3: return launch_sgemv_nb<3, CG, G, ROLE>(a, st);
+        case 4: return launch_sgemv_nb<4, CG, G, ROLE>(a, st);
+        case 5: return launch_sgemv_nb<5, CG, G, ROLE>(a, st);
+        case 6: return launch_sgemv_nb<6, CG, G, ROLE>(a, st);
+        case 7: return launch_sgemv_nb<7, CG, G, ROLE>(a, st);
+        case 8: return launch_sgemv_nb<8, CG, G, ROLE>(a, st);
+        default: set_error("k_sgemv: %d rows (1..8)", rows); return WMAR_EINVAL;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- attention, head_dim 64
+struct SaArgs {
+    const float* q;        // [rows][D]
+    const float* kcache;   // this layer's [Bmax][H][Tmax][64]; the new row is already appended (k_sgemv<QKV>)
+    const float* vcache;
+    float* y;              // [rows][D]
+    const int* pos_dev;
+    int H, Tmax, D;
+    float scale;
+};
+
+// NU units of 4 cached rows per wave and trip, all requested before the first is used (a cache row is 16 lanes x 16 bytes)
+template <int NU>
+__device__ __forceinline__ void sattn_rows(const float4* __restrict__ Kp, const float4* __restrict__ Vp, int T, int u0, int rr,
+                                           const float4 q4, float scale, float& m, float& l, float4& o) {
+    float4 kb[NU], vb[NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        int row = 4 * (u0 + 4 * i) + rr;
+        row = row < T ? row : T - 1;
+        kb[i] = ld_nt(Kp + (long long)row * 16);
+        vb[i] = ld_nt(Vp + (long long)row * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        float s = q4.x * kb[i].x + q4.y * kb[i].y + q4.z * kb[i].z + q4.w * kb[i].w;
+        s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+        s *= scale;
+        if (4 * (u0 + 4 * i) + rr < T) {
+            const float mn = fmaxf(m, s);
+            const float corr = expf(m - mn), pe = expf(s - mn);      // m = -inf at the first row: corr = 0
+            l = l * corr + pe;
+            o.x = o.x * corr + pe * vb[i].x; o.y = o.y * corr + pe * vb[i].y;
+            o.z = o.z * corr + pe * vb[i].z; o.w = o.w * corr + pe * vb[i].w;
+            m = mn;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sattn(SaArgs a) {
+    __shared__ float sm[16], sl[16];
+    __shared__ __attribute__((aligned(16))) float so[16][64];
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, p = lane & 15, rr = lane >> 4;
+    const int T = *a.pos_dev + 1;
+    const float4 q4 = *((const float4*)(a.q + (long long)b * a.D + h * 64) + p);
+    const long long base = ((long long)b * a.H + h) * a.Tmax * 64;
+    const float4* Kp = (const float4*)(a.kcache + base) + p;
+    const float4* Vp = (const float4*)(a.vcache + base) + p;
+    float m = -INFINITY, l = 0.f;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int nu = (T + 3) >> 2;               // units of 4 rows; wave w takes units w, w + 4, ...
+    if (nu <= 16) {
+        if (w < nu) sattn_rows<4>(Kp, Vp, T, w, rr, q4, a.scale, m, l, o);
+    } else {
+        for (int u0 = w; u0 < nu; u0 += 64) sattn_rows<16>(Kp, Vp, T, u0, rr, q4, a.scale, m, l, o);
+    }
+    const int gi = w * 4 + rr;
+    if (p == 0) { sm[gi] = m; sl[gi] = l; }
+    *((float4*)&so[gi][p * 4]) = o;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float M = sm[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) M = fmaxf(M, sm[i]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float e = expf(sm[i] - M);            // groups without a row: exp(-inf) = 0
+            L += sl[i] * e;
+            O += so[i][threadIdx.x] * e;
+        }
+        a.y[(long long)b * a.D + h * 64 + threadIdx.x] = O / L;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- token + position embedding
+struct SeArgs {
+    const float* tok_emb; const float* pos_emb; float* x;
+    const long long* tok; long long tok_stride; int tok_use_pos;
+    const int* pos_dev; int D;
+};
+__global__ __launch_bounds__(256) void k_sembed(SeArgs a) {
+    const int b = blockIdx.y;
+    const int k4 = blockIdx.x * 256 + threadIdx.x;
+    if (k4 * 4 >= a.D) return;
+    const int pos = *a.pos_dev;
+    const long long tk = a.tok[(long long)b * a.tok_stride + (a.tok_use_pos ? pos : 0)];
+    const float4 e = *((const float4*)(a.tok_emb + tk * a.D) + k4);
+    const float4 pe = *((const float4*)(a.pos_emb + (long long)pos * a.D) + k4);
+    *((float4*)(a.x + (long long)b * a.D) + k4) = make_float4(e.x + pe.x, e.y + pe.y, e.z + pe.z, e.w + pe.w);
+}
+
+}  // namespace wmar

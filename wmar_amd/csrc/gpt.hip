@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "decoder_host.h"
+#include "decode_small.h"
 
 
 using namespace wmar;
@@ -36,12 +37,24 @@ struct LayerW {
     float *bqkv, *bproj, *bfc1, *bfc2, *cqkv, *cfc1;
 };
 
+// Row-major weights of the small-batch path (decode_small.h): the checkpoint's own layout, LayerNorm NOT folded.
+struct SmallW {
+    float *wqkv = nullptr, *bqkv = nullptr, *wproj = nullptr, *wfc1 = nullptr, *bfc1 = nullptr, *wfc2 = nullptr;
+    float *ln1w = nullptr, *ln1b = nullptr, *ln2w = nullptr, *ln2b = nullptr;
+};
+
 struct wmar_gpt {
     wmar_gpt_config cfg{};
     int D = 0, H = 0, hd = 0, V = 0, L = 0, Tmax = 0, Bmax = 0, MTmax = 0;
     std::vector<void*> allocs;
     int64_t bytes = 0;
     std::vector<LayerW> layers;
+    // small-batch path (1..8 rows, n_embd 1536, head_dim 64): streaming kernels on row-major weights, five launches per layer
+    std::vector<SmallW> sw;
+    float *whead_rm = nullptr, *lnfw = nullptr, *lnfb = nullptr;
+    float *xs = nullptr, *ys = nullptr, *hs = nullptr, *qs = nullptr;     // [8][D], [8][D], [8][4D], [8][D] row-major
+    bool small_ok = false;
+    bool xr_enqueued = false;      // a fused projection launch (k_bx_xr) was enqueued since the last flag check
     float *tok_emb = nullptr, *pos_emb = nullptr, *bhead = nullptr, *chead = nullptr;
     float4* whead = nullptr;
     // workspaces
@@ -200,8 +213,10 @@ struct StepPlan {
     bool proj_bx = false;     // 33..64 rows, n_embd a multiple of 384: output projection as k_bx on the attention's bf16 pieces
     bool proj_xr = false;     // ... with the residual fold + LN2 statistics inside the launch (k_bx_xr): no k_resid_stats behind it
     int nch_ln2 = 0;          // statistics chunks the FC1 launch reads (16 = two per XCD group behind k_bx_xr)
+    bool small = false;       // 1..8 rows on an eligible engine: the streaming path of decode_small.h
 
     StepPlan(wmar_gpt* g_, int64_t B_, const StepIO& io_, hipStream_t st_) : g(g_), B(B_), io(io_), st(st_) {
+        small = B <= SG_MAX_ROWS && g->small_ok;
         MT = mt_for(B); D = g->D; KBD = D / 8; KBF = 4 * D / 8; nch = stat_chunks(KBD);
         act = (long long)KBD * MT * 64;  // float4 units of one [M][D] packed activation
         r.x = g->x; r.stats = g->stats; r.KB = KBD; r.MT = MT; r.n_chunks = nch;
@@ -255,7 +270,19 @@ struct StepPlan {
         a.pos_dev = g->pos_dev; a.D = D; a.H = g->H; a.hd = g->hd; a.Tmax = g->Tmax;
         return a;
     }
+    SgArgs sg_base() const {
+        SgArgs a{};
+        a.pos_dev = g->pos_dev; a.D = D; a.H = g->H; a.Tmax = g->Tmax;
+        return a;
+    }
     int embed() {
+        if (small) {
+            SeArgs e{g->tok_emb, g->pos_emb, g->xs, io.tok, io.tok_stride, io.tok_use_pos, g->pos_dev, D};
+            g->span_begin(WMAR_T_EMBED, st);
+            hipLaunchKernelGGL(k_sembed, dim3((unsigned)((D / 4 + 255) / 256), (unsigned)B), dim3(256), 0, st, e);
+            g->span_end(st);
+            return launch_status("k_sembed");
+        }
         r.x = xcur;
         g->span_begin(WMAR_T_EMBED, st);
         hipLaunchKernelGGL((k_resid_stats<true, 0>), dim3(nch * MT), dim3(256), 0, st, r);
@@ -298,6 +325,17 @@ struct StepPlan {
         xcur = xout;
         return rc;
     }
+    int qkv_small(int l) {
+        const SmallW& w = g->sw[l];
+        const long long lstride = (long long)g->Bmax * g->H * g->Tmax * g->hd;
+        SgArgs a = sg_base();
+        a.W = w.wqkv; a.bias = w.bqkv; a.x = g->xs; a.gamma = w.ln1w; a.beta = w.ln1b; a.out = g->qs;
+        a.kcache = g->kcache + l * lstride; a.vcache = g->vcache + l * lstride; a.N = 3 * D; a.K = D;
+        g->span_begin(WMAR_T_QKV, st);
+        const int rc = launch_sgemv<3, 3, SG_QKV>(a, (int)B, st);
+        g->span_end(st);
+        return rc;
+    }
     int qkv(int l) {
         GemmArgs a = base();
         const LayerW& w = g->layers[l];
@@ -312,6 +350,13 @@ struct StepPlan {
     int attn(int l) {
         const LayerW& w = g->layers[l];
         const long long lstride = (long long)g->Bmax * g->H * g->Tmax * g->hd;
+        if (small) {
+            SaArgs s{g->qs, g->kcache + l * lstride, g->vcache + l * lstride, g->ys, g->pos_dev, g->H, g->Tmax, D, 1.0f / sqrtf((float)g->hd)};
+            g->span_begin(WMAR_T_ATTN, st);
+            hipLaunchKernelGGL(k_sattn, dim3((unsigned)(B * g->H)), dim3(256), 0, st, s);
+            g->span_end(st);
+            return launch_status("k_sattn");
+        }
         AttnArgs t{};
         t.qkv_slabs = g->qkv_slabs; t.slab_stride = 3 * act; t.K = D; t.invK = 1.0 / (double)D;
         if (S_qx > 0) { t.S = S_qx; t.stats = g->stats_q; t.n_chunks = qkv_bx() ? S_qx * qx_nkeep() : S_qx; }
@@ -350,6 +395,14 @@ struct StepPlan {
     }
     // attention output projection (split-K slabs; bias + residual folded by the next resid())
     int proj(int l) {
+        if (small) {
+            SgArgs a = sg_base();
+            a.W = g->sw[l].wproj; a.bias = g->layers[l].bproj; a.x = g->ys; a.out = g->xs; a.N = D; a.K = D;
+            g->span_begin(WMAR_T_PROJ, st);
+            const int rc = launch_sgemv<3, 1, SG_PROJ>(a, (int)B, st);
+            g->span_end(st);
+            return rc;
+        }
         if (proj_xr) {
             BxrArgs q{};
             BxArgs& x = q.bx;
@@ -362,6 +415,7 @@ struct StepPlan {
             // same-box A/B); WMAR_XR_NW4=1 keeps four waves x 6 steps
             static const bool xr4 = getenv("WMAR_XR_NW4") != nullptr;
             const int rc = xr4 ? launch_bx_xr<BX_PER, 4>(q, D, st) : launch_bx_xr<BX_PER / 2, 4, 8>(q, D, st);
+            g->xr_enqueued = true;
             g->span_end(st);
             return rc;
         }
@@ -384,6 +438,15 @@ struct StepPlan {
     }
     // LN2 -> FC1 (+bias, GELU) -> packed hidden
     int fc1(int l) {
+        if (small) {
+            const SmallW& sw = g->sw[l];
+            SgArgs a = sg_base();
+            a.W = sw.wfc1; a.bias = sw.bfc1; a.x = g->xs; a.gamma = sw.ln2w; a.beta = sw.ln2b; a.out = g->hs; a.N = 4 * D; a.K = D;
+            g->span_begin(WMAR_T_FC1, st);
+            const int rc = launch_sgemv<3, 4, SG_FC1>(a, (int)B, st);
+            g->span_end(st);
+            return rc;
+        }
         GemmArgs f = base();
         const LayerW& w = g->layers[l];
         f.Wp = w.wfc1; f.Xp = xcur; f.bias = w.bfc1; f.c1 = w.cfc1; f.KB = KBD; f.NT = 4 * D / 32;
@@ -404,6 +467,14 @@ struct StepPlan {
         return rc;
     }
     int fc2(int l) {
+        if (small) {
+            SgArgs a = sg_base();
+            a.W = g->sw[l].wfc2; a.bias = g->layers[l].bfc2; a.x = g->hs; a.out = g->xs; a.N = D; a.K = 4 * D;
+            g->span_begin(WMAR_T_FC2, st);
+            const int rc = launch_sgemv<3, 2, SG_FC2>(a, (int)B, st);
+            g->span_end(st);
+            return rc;
+        }
         GemmArgs q = base();
         q.Wp = g->layers[l].wfc2; q.Xp = g->hbuf; q.KB = KBF; q.NT = D / 32;
         q.out_packed = g->slabs; q.slab_stride = act; q.n_hi = fc2_hi;
@@ -416,6 +487,14 @@ struct StepPlan {
     }
     // ln_f -> vocabulary head
     int head() {
+        if (small) {
+            SgArgs a = sg_base();
+            a.W = g->whead_rm; a.x = g->xs; a.gamma = g->lnfw; a.beta = g->lnfb; a.out = io.logits; a.N = g->V; a.K = D;
+            g->span_begin(WMAR_T_HEAD, st);
+            const int rc = launch_sgemv<4, 8, SG_HEAD>(a, (int)B, st);
+            g->span_end(st);
+            return rc;
+        }
         GemmArgs h = base();
         h.Wp = g->whead; h.Xp = xcur; h.KB = KBD; h.NT = g->V / 32;
         h.bias = g->bhead; h.c1 = g->chead; h.logits = io.logits; h.V = g->V;
@@ -456,6 +535,17 @@ int enqueue_step(wmar_gpt* g, int64_t B, const StepIO& io, hipStream_t st) {
     if (g->dbg_sums) { g->dbg_slot = 0; if (hipMemsetAsync(g->dbg_sums, 0, 4096 * 8, st) != hipSuccess) return WMAR_EHIP; }
 #endif
     if ((rc = p.embed())) return rc;
+    if (p.small) {
+        // 1..8 rows: five streaming launches per layer, the residual stream updated in place (decode_small.h)
+        for (int l = 0; l < g->L; ++l) {
+            if ((rc = p.qkv_small(l))) return rc;
+            if ((rc = p.attn(l))) return rc;
+            if ((rc = p.proj(l))) return rc;
+            if ((rc = p.fc1(l))) return rc;
+            if ((rc = p.fc2(l))) return rc;
+        }
+        return p.head();
+    }
     p.dbg(p.xcur, actb); p.dbg(g->stats, p.nch * Mpad * 16);                                   // slots 0, 1
     for (int l = 0; l < g->L; ++l) {                                                            // then 11 per layer:
         if (p.S_qx > 0) {
@@ -614,6 +704,44 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
         TRY(pack(f2w, w.wfc2, D, 4 * D, 0, st));
         TRY(copy_vec(g, &w.bfc2, f2b, D, st));
     }
+    // small-batch path (decode_small.h): the weights once more in the checkpoint's row-major layout (LayerNorm not folded), 5.5 GB at
+    // 48 layers x 1536.  Shapes: n_embd = two K segments of 768, head_dim 64.  WMAR_NO_SMALL=1 at creation keeps 1..8 rows on the
+    // matrix-core plan (A/B, tests).
+    if (rc == WMAR_OK && D == 2 * SG_SEG && hd == 64 && !getenv("WMAR_NO_SMALL")) {
+        g->sw.resize(L);
+        const size_t DD = (size_t)D * D;
+        for (int l = 0; l < L && rc == WMAR_OK; ++l) {
+            std::string p = "blocks." + std::to_string(l) + ".";
+            SmallW& w = g->sw[l];
+            TRY(g->alloc(&w.wqkv, 3 * DD));
+            TRY(g->alloc(&w.bqkv, (size_t)3 * D));
+            if (rc == WMAR_OK) {
+                const char* nm[3] = {"attn.query", "attn.key", "attn.value"};
+                hipError_t e = hipSuccess;
+                for (int i = 0; i < 3 && e == hipSuccess; ++i) {
+                    e = hipMemcpyAsync(w.wqkv + i * DD, tm.get(p + nm[i] + ".weight"), DD * 4, hipMemcpyDeviceToDevice, st);
+                    if (e == hipSuccess) e = hipMemcpyAsync(w.bqkv + (size_t)i * D, tm.get(p + nm[i] + ".bias"), (size_t)D * 4, hipMemcpyDeviceToDevice, st);
+                }
+                if (e != hipSuccess) { set_error("gpt_create: %s", hipGetErrorString(e)); rc = WMAR_EHIP; }
+            }
+            TRY(copy_vec(g, &w.wproj, tm.get(p + "attn.proj.weight"), DD, st));
+            TRY(copy_vec(g, &w.wfc1, tm.get(p + "mlp.0.weight"), 4 * DD, st));
+            TRY(copy_vec(g, &w.bfc1, tm.get(p + "mlp.0.bias"), (size_t)4 * D, st));
+            TRY(copy_vec(g, &w.wfc2, tm.get(p + "mlp.2.weight"), 4 * DD, st));
+            TRY(copy_vec(g, &w.ln1w, tm.get(p + "ln1.weight"), D, st));
+            TRY(copy_vec(g, &w.ln1b, tm.get(p + "ln1.bias"), D, st));
+            TRY(copy_vec(g, &w.ln2w, tm.get(p + "ln2.weight"), D, st));
+            TRY(copy_vec(g, &w.ln2b, tm.get(p + "ln2.bias"), D, st));
+        }
+        TRY(copy_vec(g, &g->whead_rm, hw, (size_t)V * D, st));
+        TRY(copy_vec(g, &g->lnfw, lfw, D, st));
+        TRY(copy_vec(g, &g->lnfb, lfb, D, st));
+        TRY(g->alloc(&g->xs, (size_t)SG_MAX_ROWS * D));
+        TRY(g->alloc(&g->ys, (size_t)SG_MAX_ROWS * D));
+        TRY(g->alloc(&g->hs, (size_t)SG_MAX_ROWS * 4 * D));
+        TRY(g->alloc(&g->qs, (size_t)SG_MAX_ROWS * D));
+        g->small_ok = rc == WMAR_OK;
+    }
     const size_t Mpad = (size_t)g->MTmax * 32;
     TRY(g->alloc(&g->x, Mpad * D / 4));
     TRY(g->alloc(&g->x2, Mpad * D / 4));
@@ -687,7 +815,10 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
 // Returns 1 when a flag was up: the engine has then been switched to the two-launch path (k_bx + k_resid_stats), its graphs dropped
 // and the flags cleared -- the caller re-runs its work, which is deterministic in its inputs.  0: clean.  < 0: HIP error.
 static int gpt_sync_failed(wmar_gpt* g, hipStream_t st) {
-    if (!g->xsync || !g->xcd_ok) return 0;
+    // only a fused launch can raise the flags: calls that enqueued none (two-launch path, WMAR_NO_XR, <= 32 rows, the small-batch
+    // path) stay asynchronous and legal inside a caller's stream capture
+    if (!g->xsync || !g->xcd_ok || g->no_xr || !g->xr_enqueued) return 0;
+    g->xr_enqueued = false;
     unsigned f[2] = {0, 0};
     WMAR_HIP_CHECK(hipMemcpyAsync(f, g->xsync + 8 * 64, 8, hipMemcpyDeviceToHost, st));
     WMAR_HIP_CHECK(hipStreamSynchronize(st));
@@ -762,10 +893,10 @@ int wmar_gpt_profile_role(wmar_gpt* g, int32_t role, int64_t B, int32_t kv_len, 
         const int l = it % ncycle;
         switch (role) {
             case WMAR_T_EMBED: return p.embed();
-            case WMAR_T_QKV: p.xcur = g->x; return p.S_qx > 0 ? p.qkvx(l, g->layers[l].bfc2) : p.qkv(l);
+            case WMAR_T_QKV: if (p.small) return p.qkv_small(l); p.xcur = g->x; return p.S_qx > 0 ? p.qkvx(l, g->layers[l].bfc2) : p.qkv(l);
             case WMAR_T_ATTN: return p.attn(l);
             case WMAR_T_PROJ: return p.proj(l);
-            case WMAR_T_RESID: return p.resid(g->layers[l].bproj, p.S_proj);
+            case WMAR_T_RESID: if (p.small) { set_error("profile_role: the small-batch path has no residual launch"); return WMAR_EINVAL; } return p.resid(g->layers[l].bproj, p.S_proj);
             case WMAR_T_FC1: return p.fc1(l);
             case WMAR_T_FC2: return p.fc2(l);
             case WMAR_T_HEAD: return p.head();
@@ -793,6 +924,16 @@ int wmar_gpt_plan_info(wmar_gpt* g, int64_t B, char* buf, int64_t buf_len) {
     WMAR_REQUIRE(B >= 1 && B <= g->Bmax, "plan_info: batch outside 1..%d", g->Bmax);
     StepIO io{g->past, (long long)g->Tmax + 1, 0, g->logits};
     StepPlan p(g, B, io, nullptr);
+    if (p.small) {
+        const int n = snprintf(buf, (size_t)buf_len,
+                               "qkv=k_sgemv<QKV> (row-major weight stream, LN1 + bias + cache append inside, %d columns per workgroup);"
+                               "attn=k_sattn (4 waves per (sequence, head));proj=k_sgemv<PROJ> (residual added in place);resid=none;"
+                               "resid_launches_per_step=0;fc1=k_sgemv<FC1> (LN2 + bias + GELU inside);fc2=k_sgemv<FC2> (8 K segments, residual added in place);"
+                               "head=k_sgemv<HEAD> (ln_f inside);barrier_fallbacks=%d;path=small-batch streaming (decode_small.h)",
+                               sg_cols_wg<3, 3, SG_QKV>(), g->fallbacks);
+        WMAR_REQUIRE(n > 0 && n < buf_len, "plan_info: buffer of %lld bytes too small", (long long)buf_len);
+        return WMAR_OK;
+    }
     const LayerW& w = g->layers[0];
     char qkv[96], proj[160], fc1[96], fc2[96];
     const int S_in = p.S_fc2 + (p.fc2_hi > 0 ? 1 : 0);
@@ -982,6 +1123,7 @@ static int gpt_generate_once(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_samp
         if (e == hipSuccess) e = hipEventRecord(g->ev1, st);   // also marks "replays finished" for drop_graph()
         if (e == hipSuccess) { g->pending = true; }
         if (e != hipSuccess) { set_error("graph replay failed: %s", hipGetErrorString(e)); return WMAR_EHIP; }
+        { StepPlan pl(g, B, io, nullptr); if (!pl.small && pl.proj_xr) g->xr_enqueued = true; }   // a replay runs the fused launches of its capture
         // asynchronous: the caller's stream orders everything after the replays
         if (g->timing) WMAR_HIP_CHECK(hipEventSynchronize(g->ev1));
     } else {
