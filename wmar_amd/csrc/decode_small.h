@@ -118,7 +118,18 @@ __global__ __launch_bounds__(ROLE == SG_FC2 ? 512 : 256) void k_sgemv(SgArgs a) 
             _Pragma("unroll") for (int ch = 0; ch < CH; ++ch) BUF[c * CH + ch] = ld_nt(p_ + ch * 64); \
         }                                                                                      \
     }
-    WMAR_SG_LOADW(wbuf[0], 0)
+
+    // the epilogue's operands (bias, the residual value a column owner adds to) are requested here, not behind the reduction: a
+    // dependent global round trip at the end of every launch otherwise (~1 us of each launch's ~4 us fixed cost)
+    const int et = threadIdx.x;
+    const int eb = et / cols_wg, ecol = et - eb * cols_wg;
+    const int en = blockIdx.x * cols_wg + ecol;
+    const bool eon = ROLE != SG_HEAD && et < cols_wg * NB && en < a.N;
+    float ebias = 0.f, eold = 0.f;
+    if (eon) {
+        ebias = a.bias[en];
+        if (ROLE == SG_PROJ || ROLE == SG_FC2) eold = a.out[(long long)eb * a.N + en];
+    }
 
     // this wave's slice of the input rows (and of the LayerNorm parameters)
     float4 xr[CH][NB];
@@ -129,6 +140,9 @@ __global__ __launch_bounds__(ROLE == SG_FC2 ? 512 : 256) void k_sgemv(SgArgs a) 
 #pragma unroll
             for (int ch = 0; ch < CH; ++ch) xr[ch][b] = *((const float4*)(xb + (long long)b * K) + ch * 64);
     }
+    // the rows are on the critical path (statistics, then the first multiply); two weight groups go out right behind them
+    WMAR_SG_LOADW(wbuf[0], 0)
+    if (G > 1) WMAR_SG_LOADW(wbuf[1], 1)
     if (LN) {
         float4 gm[CH], bt[CH];
 #pragma unroll
@@ -197,41 +211,46 @@ __global__ __launch_bounds__(ROLE == SG_FC2 ? 512 : 256) void k_sgemv(SgArgs a) 
         }                                                                                      \
     }
 
-    // column groups: the next group's weights are requested before the current group is used
+    // column groups: two groups in flight; group g + 2 is requested into the buffer group g has just been multiplied out of
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        if (g + 1 < G) WMAR_SG_LOADW(wbuf[(g + 1) & 1], g + 1)
         WMAR_SG_COMPUTE(wbuf[g & 1], g)
+        if (g + 2 < G) WMAR_SG_LOADW(wbuf[g & 1], g + 2)
     }
 #undef WMAR_SG_LOADW
 #undef WMAR_SG_COMPUTE
     __syncthreads();
 
     // segment sums in a fixed order + epilogue; column fastest so that the stores of a row are contiguous
-    const int pos = (ROLE == SG_QKV) ? *a.pos_dev : 0;
-    for (int t = threadIdx.x; t < cols_wg * NB; t += NW * 64) {
-        const int b = t / cols_wg, col = t - b * cols_wg;
-        const int n = blockIdx.x * cols_wg + col;
-        if (n >= a.N) continue;
-        float s = part[(long long)col * NB + b];
+    if (ROLE == SG_HEAD) {
+        for (int t = threadIdx.x; t < cols_wg * NB; t += NW * 64) {
+            const int b = t / cols_wg, col = t - b * cols_wg;
+            const int n = blockIdx.x * cols_wg + col;
+            if (n >= a.N) continue;
+            float s = part[(long long)col * NB + b];
 #pragma unroll
-        for (int sg = 1; sg < NSEG; ++sg) s += part[((long long)sg * cols_wg + col) * NB + b];
-        if (ROLE != SG_HEAD) s += a.bias[n];
+            for (int sg = 1; sg < NSEG; ++sg) s += part[((long long)sg * cols_wg + col) * NB + b];
+            a.out[(long long)b * a.N + n] = s;
+        }
+    } else if (eon) {
+        static_assert(ROLE == SG_HEAD || cols_wg * SG_MAX_ROWS <= NW * 64, "one epilogue value per thread");
+        float s = part[(long long)ecol * NB + eb];
+#pragma unroll
+        for (int sg = 1; sg < NSEG; ++sg) s += part[((long long)sg * cols_wg + ecol) * NB + eb];
+        s += ebias;
         if (ROLE == SG_QKV) {
-            const int which = n / a.D, j = n - which * a.D;
-            if (which == 0) a.out[(long long)b * a.D + j] = s;
+            const int pos = *a.pos_dev;
+            const int which = en / a.D, j = en - which * a.D;
+            if (which == 0) a.out[(long long)eb * a.D + j] = s;
             else {
                 const int h = j >> 6, d = j & 63;
                 float* cache = which == 1 ? a.kcache : a.vcache;
-                cache[(((long long)b * a.H + h) * a.Tmax + pos) * 64 + d] = s;
+                cache[(((long long)eb * a.H + h) * a.Tmax + pos) * 64 + d] = s;
             }
         } else if (ROLE == SG_PROJ || ROLE == SG_FC2) {
-            float* o = a.out + (long long)b * a.N + n;
-            *o = *o + s;
-        } else if (ROLE == SG_FC1) {
-            a.out[(long long)b * a.N + n] = gelu_erf(s);
+            a.out[(long long)eb * a.N + en] = eold + s;
         } else {
-            a.out[(long long)b * a.N + n] = s;
+            a.out[(long long)eb * a.N + en] = gelu_erf(s);
         }
     }
 }
@@ -279,7 +298,9 @@ struct SaArgs {
     float scale;
 };
 
-// NU units of 4 cached rows per wave and trip, all requested before the first is used (a cache row is 16 lanes x 16 bytes)
+// NU units of 4 cached rows per wave and trip, all requested before the first is used (a cache row is 16 lanes x 16 bytes).  Two
+// passes without a branch: all NU scores first (independent 16-lane reductions the compiler interleaves), one maximum, NU independent
+// exponentials, then the weighted V sum; the running (max, sum, V sum) is touched once per trip, not once per row.
 template <int NU>
 __device__ __forceinline__ void sattn_rows(const float4* __restrict__ Kp, const float4* __restrict__ Vp, int T, int u0, int rr,
                                            const float4 q4, float scale, float& m, float& l, float4& o) {
@@ -291,20 +312,30 @@ __device__ __forceinline__ void sattn_rows(const float4* __restrict__ Kp, const 
         kb[i] = ld_nt(Kp + (long long)row * 16);
         vb[i] = ld_nt(Vp + (long long)row * 16);
     }
+    float sc[NU];
+    float mt = -INFINITY;
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
         float s = q4.x * kb[i].x + q4.y * kb[i].y + q4.z * kb[i].z + q4.w * kb[i].w;
         s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
-        s *= scale;
-        if (4 * (u0 + 4 * i) + rr < T) {
-            const float mn = fmaxf(m, s);
-            const float corr = expf(m - mn), pe = expf(s - mn);      // m = -inf at the first row: corr = 0
-            l = l * corr + pe;
-            o.x = o.x * corr + pe * vb[i].x; o.y = o.y * corr + pe * vb[i].y;
-            o.z = o.z * corr + pe * vb[i].z; o.w = o.w * corr + pe * vb[i].w;
-            m = mn;
-        }
+        s = (4 * (u0 + 4 * i) + rr < T) ? s * scale : -INFINITY;
+        sc[i] = s;
+        mt = fmaxf(mt, s);
     }
+    const float mn = fmaxf(m, mt);
+    const float ms = mn == -INFINITY ? 0.f : mn;        // a row group without a valid row so far: every weight below is exp(-inf) = 0
+    const float corr = expf(m - ms);
+    float lt = 0.f;
+    float4 ot = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const float pe = expf(sc[i] - ms);
+        lt += pe;
+        ot.x += pe * vb[i].x; ot.y += pe * vb[i].y; ot.z += pe * vb[i].z; ot.w += pe * vb[i].w;
+    }
+    l = l * corr + lt;
+    o.x = o.x * corr + ot.x; o.y = o.y * corr + ot.y; o.z = o.z * corr + ot.z; o.w = o.w * corr + ot.w;
+    m = mn;
 }
 
 __global__ __launch_bounds__(256) void k_sattn(SaArgs a) {
