@@ -186,6 +186,46 @@ def parity_block(log):
     return out
 
 
+def small_batch_block(model, wm, gcfg, log):
+    """The reference's OWN batch sizes on the same 48-layer engine: BASELINE.json configs[0] (batch 1) and the published run's batch 5
+    (configs/taming_generate.json).  Full unit of work -- sample 256 tokens (watermark + top-k + top-p inside the captured loop) ->
+    codes_to_images -> images_to_codes -> detect -- one warm-up + best of two.  These rows run the weight-streaming plan of
+    wmar_amd/csrc/decode_small.h; the floor is the step's byte stream: 5.54 GB of fp32 weights + the K/V rows of the batch, at 8 TB/s."""
+    out = {}
+    eng = model.model.transformer
+    L, D, V = gcfg.n_layer, gcfg.n_embd, gcfg.vocab_size
+    classes = [1, 9, 232, 340, 568]                      # configs/taming_generate.json
+    for name, Bs in (("taming_b1", 1), ("taming_b5", 5)):
+        cond = torch.tensor(classes[:Bs], device=model.model.device)
+        best = None
+        for rep in range(3):
+            q = model.draw_noise(256, Bs)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            codes = model.sample(cond, dict(batch_size=Bs, temperature=1.0, top_k=250, top_p=0.92), apply_watermark=True, q=q)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            img = model.codes_to_images(codes); torch.cuda.synchronize(); t2 = time.perf_counter()
+            c2 = model.images_to_codes(img); torch.cuda.synchronize(); t3 = time.perf_counter()
+            pv = wm.detect(c2); torch.cuda.synchronize(); t4 = time.perf_counter()
+            r = {"images_per_s": round(Bs / (t4 - t0), 3), "ms_per_step": round((t1 - t0) / 256 * 1e3, 3), "sample_s": round(t1 - t0, 4),
+                 "vq_decode_s": round(t2 - t1, 4), "vq_encode_s": round(t3 - t2, 4), "detect_s": round(t4 - t3, 5)}
+            if rep > 0 and (best is None or r["ms_per_step"] < best["ms_per_step"]):
+                best = r
+        wbytes = 4.0 * (12 * D * D * L + D * V)
+        floor_ms = (wbytes + 2.0 * L * D * 4 * 128.5 * Bs) / (PEAK_HBM_GBS * 1e9) * 1e3
+        plan = eng.plan_info(Bs)
+        roles = {}
+        for k, wb in (("qkv", 3 * D * D * 4.0), ("attn", 2.0 * Bs * D * 4 * 128), ("proj", D * D * 4.0), ("fc1", 4 * D * D * 4.0), ("fc2", 4 * D * D * 4.0), ("head", D * V * 4.0)):
+            us = eng.profile_role(k, Bs, kv_len=128, iters=2 * L)
+            roles[k] = {"kernel": plan.get(k, ""), "avg_us": round(us, 2), "bytes_per_launch": wb, "GBs": round(wb / us * 1e-3, 1),
+                        "frac_of_hbm": round(wb / us * 1e-3 / PEAK_HBM_GBS, 3)}
+        best.update(config=f"Taming cin_transformer 48L x 1536d + VQGAN f16/16384, 256x256, batch {Bs}, greenlist delta=2 gamma=.25 h=1, "
+                           "T=1 top-k 250 top-p 0.92; sample -> decode -> re-encode -> detect", plan=plan.get("path", "matrix-core plan"),
+                    step_floor_ms=round(floor_ms, 3), frac_of_step_floor=round(floor_ms / best["ms_per_step"], 3), roles=roles)
+        out[name] = best
+        log(f"small batch {name}: {best['ms_per_step']} ms per step = {best['frac_of_step_floor']} of the byte-stream floor, {best['images_per_s']} images/s")
+    return out
+
+
 def secondary_block(log, device="cuda"):
     """BASELINE.json configs[2] and configs[3] on the same GPU, AFTER the timed region and after the Taming engines are released
     (driver-verifiable numbers for the two other model families; skip with --no-secondary):
@@ -496,12 +536,20 @@ def main():
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(extra["gs"], extra["vs"], extra["gcfg"], extra["vcfg"], wm, log)
             out["secondary"] = None
+            small = None
+            if world == 1 and not args.no_secondary:
+                try:
+                    small = small_batch_block(model, wm, extra["gcfg"], log)
+                except Exception as e:      # a secondary config must never cost the headline line
+                    small = {"taming_small_batch_error": repr(e)}
             if world == 1 and not args.no_secondary:
                 # the Taming engines (22.6 GB) are released first: the 7B model + its KV cache need 40 GB of their own
                 import gc
                 del model, wm, extra
                 gc.collect(); torch.cuda.empty_cache()
                 out["secondary"] = secondary_block(log, device)
+                if small:
+                    out["secondary"].update(small)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

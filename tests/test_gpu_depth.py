@@ -56,7 +56,9 @@ def test_taming_48_layers_teacher_forced_logits(gpt48):
     eng, sd = gpt48
     cfg = synth.TAMING_GPT
     rs = np.random.RandomState(48)
-    for rows, T, positions in ((64, 40, [0, 1, 39]), (8, 256, [113, 255])):
+    # 64 rows: the benchmark's matrix-core plan; 8 / 5 / 1 rows: the weight-streaming plan of decode_small.h (the reference's own
+    # batch sizes are 1 and 5: BASELINE configs[0], configs/taming_generate.json)
+    for rows, T, positions in ((64, 40, [0, 1, 39]), (8, 256, [113, 255]), (5, 160, [0, 1, 159]), (1, 72, [0, 71])):
         seq = torch.from_numpy(rs.randint(0, cfg.vocab_size, size=(rows, T)).astype(np.int64))
         t0 = time.perf_counter()
         ref = M.gpt_prefix(sd, cfg.n_head, seq, positions).numpy()            # [rows, len(positions), V]
@@ -115,6 +117,30 @@ def test_taming_48_layers_watermarked_loop_tokens(gpt48, kat, key_factory):
         assert near <= 1, near
         print(f"48 layers, {'graph' if graph else 'eager'}: {B} x {steps} tokens, {int((got == ref).all(1).sum())} rows bit-equal, "
               f"{near} near-tie divergences; oracle loop {t_cpu:.1f} s")
+
+
+@pytest.mark.parametrize("B", [1, 5])
+def test_taming_48_layers_small_batch_loop_tokens(gpt48, kat, key_factory, B):
+    """the reference's own batch sizes (1: BASELINE configs[0]; 5: configs/taming_generate.json) through the 48-layer engine's
+    small-batch plan: a 48-step watermarked sampling loop, graph and eager, token for token against model_oracle.sample_with_past"""
+    eng, sd = gpt48
+    cfg = synth.TAMING_GPT
+    assert "k_sgemv" in eng.plan_info(B)["qkv"]
+    wm = _wm(kat["keys"]["taming"])
+    key = key_factory(kat["keys"]["taming"])
+    steps = 48
+    cond = torch.tensor([1, 9, 232, 340, 568][:B])
+    g = torch.Generator().manual_seed(4800 + B)
+    q = torch.empty(steps, B, cfg.vocab_size).exponential_(1, generator=g)
+    rec = []
+    ref = M.sample_with_past(sd, cfg.n_head, cond.view(-1, 1), steps, 1.0, 250, 0.92, key, 2.0,
+                             q_source=lambda n, b, v: q[n], record=rec).numpy()
+    qd = q.cuda()
+    for graph in (True, False):
+        got = eng.generate(cond.cuda(), steps, qd, 1.0, 250, 0.92, wm.wm_ctx(), use_graph=graph).cpu().numpy()
+        near = _compare_tokens(got, ref, rec, 4 * ATOL_DEPTH)
+        assert near <= 1, near
+        print(f"48 layers, batch {B}, {'graph' if graph else 'eager'}: {int((got == ref).all(1).sum())} of {B} rows bit-equal over {steps} steps, {near} near-tie divergences")
 
 
 @pytest.fixture(scope="module")

@@ -108,7 +108,8 @@ __global__ __launch_bounds__(ROLE == SG_FC2 ? 512 : 256) void k_sgemv(SgArgs a) 
     const long long K = a.K;
     const float* wbase = a.W + (long long)seg * SG_SEG + lane * 4;
 
-    float4 wbuf[2][CG * CH];
+    constexpr int NBUF = G >= 3 ? 3 : 2;                  // weight groups in flight per wave (9 or 12 KiB each)
+    float4 wbuf[NBUF][CG * CH];
 #define WMAR_SG_LOADW(BUF, GI)                                                                 \
     {                                                                                          \
         _Pragma("unroll") for (int c = 0; c < CG; ++c) {                                       \
@@ -140,27 +141,34 @@ __global__ __launch_bounds__(ROLE == SG_FC2 ? 512 : 256) void k_sgemv(SgArgs a) 
 #pragma unroll
             for (int ch = 0; ch < CH; ++ch) xr[ch][b] = *((const float4*)(xb + (long long)b * K) + ch * 64);
     }
-    // the rows are on the critical path (statistics, then the first multiply); two weight groups go out right behind them
+    // the rows are on the critical path (statistics, then the first multiply); the first weight groups go out right behind them
     WMAR_SG_LOADW(wbuf[0], 0)
     if (G > 1) WMAR_SG_LOADW(wbuf[1], 1)
+    if (G > 2) WMAR_SG_LOADW(wbuf[2], 2)
+    // Rows in PAIRS: x2[ch][component][pair] = (row 2p, row 2p + 1) -- one v_pk_fma_f32 per weight component and row pair, the weight
+    // splat over both halves (the multiply-adds are what the vector ALU spends its time on: 4 x rows per 16 weight bytes).
+    constexpr int NBP = (NB + 1) / 2;
+    f32x2 x2[CH][4][NBP];
+    float mu[NB], rstd[NB];
+    float4 gm[CH], bt[CH];
     if (LN) {
-        float4 gm[CH], bt[CH];
 #pragma unroll
         for (int ch = 0; ch < CH; ++ch) {
             gm[ch] = *((const float4*)(a.gamma + seg * SG_SEG + lane * 4) + ch * 64);
             bt[ch] = *((const float4*)(a.beta + seg * SG_SEG + lane * 4) + ch * 64);
         }
+        // per-lane partial sums of its 12 elements per row in fp32 (error <= 12 ulp of the partial), across lanes and segments in fp64
         double st[2 * NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            double s = 0.0, ss = 0.0;
+            float s = 0.f, ss = 0.f;
 #pragma unroll
             for (int ch = 0; ch < CH; ++ch) {
                 const float4 v = xr[ch][b];
-                s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
-                ss += sq4_f64(v);
+                s += (v.x + v.y) + (v.z + v.w);
+                ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
             }
-            st[2 * b] = s; st[2 * b + 1] = ss;
+            st[2 * b] = (double)s; st[2 * b + 1] = (double)ss;
         }
         int sidx;
         const double tot = wave_reduce_many<2 * NB, double>(st, lane, &sidx);
@@ -174,34 +182,48 @@ __global__ __launch_bounds__(ROLE == SG_FC2 ? 512 : 256) void k_sgemv(SgArgs a) 
             const double sm = lnred[2 * b] + lnred[NSPLIT * 2 * SG_MAX_ROWS + 2 * b];
             const double sq = lnred[2 * b + 1] + lnred[NSPLIT * 2 * SG_MAX_ROWS + 2 * b + 1];
             const double mean = sm * invK;
-            const float mu = (float)mean;
-            const float rstd = rsqrtf((float)var_f64(sq * invK, mean) + 1e-5f);
-#pragma unroll
-            for (int ch = 0; ch < CH; ++ch) {
-                float4 v = xr[ch][b];
-                v.x = (v.x - mu) * rstd * gm[ch].x + bt[ch].x;
-                v.y = (v.y - mu) * rstd * gm[ch].y + bt[ch].y;
-                v.z = (v.z - mu) * rstd * gm[ch].z + bt[ch].z;
-                v.w = (v.w - mu) * rstd * gm[ch].w + bt[ch].w;
-                xr[ch][b] = v;
-            }
+            mu[b] = (float)mean;
+            rstd[b] = rsqrtf((float)var_f64(sq * invK, mean) + 1e-5f);
         }
     }
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch)
+#pragma unroll
+        for (int bp = 0; bp < NBP; ++bp) {
+            float4 v0 = xr[ch][2 * bp], v1 = 2 * bp + 1 < NB ? xr[ch][2 * bp + 1 < NB ? 2 * bp + 1 : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (LN) {
+                const float m0 = mu[2 * bp], r0 = rstd[2 * bp];
+                v0.x = (v0.x - m0) * r0 * gm[ch].x + bt[ch].x; v0.y = (v0.y - m0) * r0 * gm[ch].y + bt[ch].y;
+                v0.z = (v0.z - m0) * r0 * gm[ch].z + bt[ch].z; v0.w = (v0.w - m0) * r0 * gm[ch].w + bt[ch].w;
+                if (2 * bp + 1 < NB) {
+                    const float m1 = mu[2 * bp + 1 < NB ? 2 * bp + 1 : 0], r1 = rstd[2 * bp + 1 < NB ? 2 * bp + 1 : 0];
+                    v1.x = (v1.x - m1) * r1 * gm[ch].x + bt[ch].x; v1.y = (v1.y - m1) * r1 * gm[ch].y + bt[ch].y;
+                    v1.z = (v1.z - m1) * r1 * gm[ch].z + bt[ch].z; v1.w = (v1.w - m1) * r1 * gm[ch].w + bt[ch].w;
+                }
+            }
+            x2[ch][0][bp] = f32x2{v0.x, v1.x}; x2[ch][1][bp] = f32x2{v0.y, v1.y};
+            x2[ch][2][bp] = f32x2{v0.z, v1.z}; x2[ch][3][bp] = f32x2{v0.w, v1.w};
+        }
 
 #define WMAR_SG_COMPUTE(BUF, GI)                                                               \
     {                                                                                          \
-        float acc[R];                                                                          \
-        _Pragma("unroll") for (int i = 0; i < R; ++i) acc[i] = 0.f;                            \
+        f32x2 acc2[CG][NBP];                                                                   \
+        _Pragma("unroll") for (int c = 0; c < CG; ++c)                                         \
+            _Pragma("unroll") for (int bp = 0; bp < NBP; ++bp) acc2[c][bp] = f32x2{0.f, 0.f};  \
         _Pragma("unroll") for (int c = 0; c < CG; ++c)                                         \
             _Pragma("unroll") for (int ch = 0; ch < CH; ++ch) {                                \
                 const float4 wv = BUF[c * CH + ch];                                            \
-                _Pragma("unroll") for (int b = 0; b < NB; ++b) {                               \
-                    float s_ = acc[c * NB + b];                                                \
-                    s_ = fmaf(wv.x, xr[ch][b].x, s_); s_ = fmaf(wv.y, xr[ch][b].y, s_);       \
-                    s_ = fmaf(wv.z, xr[ch][b].z, s_); s_ = fmaf(wv.w, xr[ch][b].w, s_);       \
-                    acc[c * NB + b] = s_;                                                      \
+                const f32x2 wx = {wv.x, wv.x}, wy = {wv.y, wv.y}, wz = {wv.z, wv.z}, ww = {wv.w, wv.w}; \
+                _Pragma("unroll") for (int bp = 0; bp < NBP; ++bp) {                           \
+                    f32x2 s_ = acc2[c][bp];                                                    \
+                    s_ = wx * x2[ch][0][bp] + s_; s_ = wy * x2[ch][1][bp] + s_;               \
+                    s_ = wz * x2[ch][2][bp] + s_; s_ = ww * x2[ch][3][bp] + s_;               \
+                    acc2[c][bp] = s_;                                                          \
                 }                                                                              \
             }                                                                                  \
+        float acc[R];                                                                          \
+        _Pragma("unroll") for (int c = 0; c < CG; ++c)                                         \
+            _Pragma("unroll") for (int b = 0; b < NB; ++b) acc[c * NB + b] = (b & 1) ? acc2[c][b >> 1].y : acc2[c][b >> 1].x; \
         int ridx;                                                                              \
         const float tot_ = wave_reduce_many<R, float>(acc, lane, &ridx);                       \
         constexpr int LBR = sg_log2p<R>();                                                     \
@@ -211,11 +233,11 @@ __global__ __launch_bounds__(ROLE == SG_FC2 ? 512 : 256) void k_sgemv(SgArgs a) 
         }                                                                                      \
     }
 
-    // column groups: two groups in flight; group g + 2 is requested into the buffer group g has just been multiplied out of
+    // column groups: NBUF groups in flight; group g + NBUF is requested into the buffer group g has just been multiplied out of
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        WMAR_SG_COMPUTE(wbuf[g & 1], g)
-        if (g + 2 < G) WMAR_SG_LOADW(wbuf[g & 1], g + 2)
+        WMAR_SG_COMPUTE(wbuf[g % NBUF], g)
+        if (g + NBUF < G) WMAR_SG_LOADW(wbuf[g % NBUF], g + NBUF)
     }
 #undef WMAR_SG_LOADW
 #undef WMAR_SG_COMPUTE
