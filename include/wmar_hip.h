@@ -396,6 +396,33 @@ int wmar_mvq_decode(wmar_mvq* v, const int64_t* codes_dev, int64_t B, float* ima
 int wmar_mvq_encode(wmar_mvq* v, const float* images_dev, int64_t B, int64_t* codes_dev, float* prequant_dev,
                     void* stream);
 
+/* ------------------------------------------------------------------------ evaluation transforms (harness)
+ * wmar/augmentations/valuemetric.py:41-140, geometric.py:22-117 as applied by generate.py:142-164: one launch over the whole batch
+ * [B, C, H, W] (fp32, contiguous).  op: 0 identity, 1 Gaussian blur (p0 = odd kernel size), 2 Gaussian noise (p0 = standard deviation,
+ * noise_dev = standard normal draws of the image shape), 3 brightness (p0 = factor), 4 rotation (p0 = counter-clockwise quarter turns,
+ * p1 = remainder in degrees, [0, 90)), 5 horizontal flip, 6 upper-left crop of p0 x p1 pixels resized back (antialiased bilinear),
+ * 7 the same crop padded back with zeros.  pm1 != 0: pixels cross this call in [-1, 1] (the decoder's range) and are transformed in
+ * [0, 1] and clamped, as generate.py:146-150 does around every transform.  JPEG stays on the host (PIL), as in the reference. */
+int wmar_augment(int32_t op, const float* in_dev, float* out_dev, const float* noise_dev, int64_t B, int32_t C, int32_t H,
+                 int32_t W, int32_t pm1, double p0, double p1, void* stream);
+
+/* ------------------------------------------------------------------------ exchange step (RCCL over xGMI)
+ * The sharded job (one process per GPU; rank r == the reference's `--chunk_id r --num_chunks world`, generate.py:204, :304) has no
+ * data-path collective.  Its two exchanges -- the finished key table from rank 0 once, the per-image records once per step
+ *  -- as thin RCCL wrappers; RCCL is resolved at run time so that a process that already carries one
+ * (PyTorch-ROCm) keeps exactly that copy.  `id` is RCCL's 128-byte unique id: made on one rank, handed to the others by the host
+ * (file, store, environment).  Buffers are device pointers, sizes in bytes; the calls are asynchronous on `stream`. */
+typedef struct wmar_comm wmar_comm;
+#define WMAR_COMM_ID_BYTES 128
+int wmar_comm_unique_id(void* id_out, int64_t id_bytes);
+int wmar_comm_init(const void* id, int64_t id_bytes, int32_t rank, int32_t world, wmar_comm** out);
+int wmar_comm_bcast(wmar_comm* c, void* buf_dev, int64_t bytes, int32_t root, void* stream);
+/* recv_dev holds world x bytes_per_rank, rank order */
+int wmar_comm_allgather(wmar_comm* c, const void* send_dev, void* recv_dev, int64_t bytes_per_rank, void* stream);
+int32_t wmar_comm_rank(const wmar_comm* c);
+int32_t wmar_comm_world(const wmar_comm* c);
+void wmar_comm_destroy(wmar_comm* c);
+
 #ifdef __cplusplus
 }
 #endif

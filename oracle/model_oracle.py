@@ -26,12 +26,17 @@ T = torch.Tensor
 
 # --------------------------------------------------------------------------- GPT
 
-def gpt_step(sd: Dict[str, T], n_head: int, idx: T, past_k, past_v, past_length: int):
+def gpt_step(sd: Dict[str, T], n_head: int, idx: T, past_k, past_v, past_length: int, cache=None):
     """GPT.forward_with_past for one new token per sequence.
     deps/taming/modules/transformer/mingpt.py:183-214 (+ Block :112-122, attention :69-95).
 
     idx [B,1] int64; past_k/past_v: lists (per layer) of [B,H,t,hd] or None.
-    Returns logits [B,V], new_k, new_v (lists of [B,H,1,hd])."""
+    Returns logits [B,V], new_k, new_v (lists of [B,H,1,hd]).
+
+    cache = (K, V), lists (per layer) of preallocated [B,H,Tmax,hd]: the new row is written at `past_length` and the attention
+    reads the view [:, :, :past_length + 1] -- the same rows as the reference's `torch.cat` (mingpt.py:80-81, :192), without
+    copying the whole cache twice per step (9.7 GB at 48 layers x 64 rows x 256 positions: 437 s -> ~70 s for a full-size loop);
+    tests/test_oracle_golden.py pins the two forms against each other.  past_k / past_v are ignored then."""
     B = idx.shape[0]
     x = sd["tok_emb.weight"][idx[:, 0]] + sd["pos_emb"][0, past_length]  # :186-200
     d = x.shape[-1]
@@ -48,7 +53,11 @@ def gpt_step(sd: Dict[str, T], n_head: int, idx: T, past_k, past_v, past_length:
         v = F.linear(h, sd[p + "attn.value.weight"], sd[p + "attn.value.bias"]).view(B, 1, n_head, hd).transpose(1, 2)
         new_k.append(k)
         new_v.append(v)
-        if past_k is not None:
+        if cache is not None:
+            cache[0][i][:, :, past_length] = k[:, :, 0]
+            cache[1][i][:, :, past_length] = v[:, :, 0]
+            kk, vv = cache[0][i][:, :, :past_length + 1], cache[1][i][:, :, :past_length + 1]
+        elif past_k is not None:
             kk = torch.cat((past_k[i], k), dim=-2)
             vv = torch.cat((past_v[i], v), dim=-2)
         else:
@@ -110,19 +119,28 @@ def default_q_source(step: int, B: int, V: int) -> T:
 @torch.no_grad()
 def sample_with_past(sd: Dict[str, T], n_head: int, cond: T, steps: int, temperature=1.0, top_k=None,
                      top_p=None, key: Optional[W.KeyParams] = None, delta: float = 0.0,
-                     q_source: Callable[[int, int, int], T] = default_q_source, record=None):
+                     q_source: Callable[[int, int, int], T] = default_q_source, record=None, static_cache: bool = False):
     """sample_with_past, deps/taming/modules/transformer/mingpt.py:326-368, with the
     logit processor of gentime_watermark.py:229-271 when `key` is given.
-    cond [B,1] int64.  Returns int64 [B, steps]."""
+    cond [B,1] int64.  Returns int64 [B, steps].  static_cache: see gpt_step (full-size loops)."""
     sample = cond.clone()
     cond_len = cond.shape[1]
     assert cond_len == 1
     pk = pv = None
     x = cond
     V = sd["head.weight"].shape[0]
+    cache = None
+    if static_cache:
+        Bc, d = cond.shape[0], sd["tok_emb.weight"].shape[1]
+        nl = 0
+        while f"blocks.{nl}.ln1.weight" in sd:
+            nl += 1
+        cache = ([torch.zeros(Bc, n_head, steps, d // n_head) for _ in range(nl)], [torch.zeros(Bc, n_head, steps, d // n_head) for _ in range(nl)])
     for n in range(steps):
-        logits, nk, nv = gpt_step(sd, n_head, x, pk, pv, n + cond_len - 1)
-        if pk is None:
+        logits, nk, nv = gpt_step(sd, n_head, x, pk, pv, n + cond_len - 1, cache=cache)
+        if cache is not None:
+            pass
+        elif pk is None:
             pk, pv = nk, nv
         else:
             pk = [torch.cat((a, b), dim=-2) for a, b in zip(pk, nk)]

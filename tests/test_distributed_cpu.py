@@ -89,3 +89,64 @@ def test_make_batches_and_seed_rule():
     assert harness.make_batches(list(range(10)), 4) == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]]
     assert harness.make_batches([], 4) == []
     assert harness.seed_everything(42, 3) == 3042
+
+
+# ------------------------------------------------------------------ BASELINE configs[4]: 512 conditionings over 8 ranks
+def _worker8(rank, world, port, q):
+    import hashlib
+
+    import numpy as np
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wmar_amd import harness
+    from wmar_amd.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
+    # the key: built on rank 0 only, broadcast, and compared on every rank with a local build (bit-equal)
+    vq = {"alive_ids": torch.arange(512), "dead_ids": torch.zeros(0, dtype=torch.long), "embedding": None}
+    wm = GentimeWatermark(vq, 512, SeedStrategy.LINEAR, SplitStrategy.RANDOM_STRATIFIED, 1, 2.0, 0.25, device="cpu")
+    table = harness.broadcast_key_table(wm, torch.device("cpu"))
+    got = hashlib.sha256(table.numpy().tobytes()).hexdigest()
+    own = hashlib.sha256(wm.key_table_host().view(np.int32).tobytes()).hexdigest()
+    inputs = [(i * 37) % 1000 for i in range(512)]          # bench.py's conditioning rule; 512 images, batch 64 -> one batch per rank
+    ev = {"metric_names": ["l0"], "augmentations": [], "max_roundtrips": 1, "orig_only": False}
+    recs = harness.generate_sharded(None, FakeModel(), inputs, None, ev, {"batch_size": 64}, seed=1)
+    hashes = [None] * world
+    dist.all_gather_object(hashes, (got, own))
+    if rank == 0:
+        q.put((recs, hashes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _single8(chunk_id):
+    from wmar_amd import harness
+    harness.seed_everything(1, chunk_id)
+    inputs = [(i * 37) % 1000 for i in range(512)]
+    ev = {"metric_names": ["l0"], "augmentations": [], "max_roundtrips": 1, "orig_only": False}
+    return harness.generate(None, FakeModel(), inputs, None, ev, {"batch_size": 64}, chunk_id=chunk_id, num_chunks=8)
+
+
+@pytest.mark.timeout(300)
+def test_eight_rank_job_equals_eight_reference_chunks_and_one_key():
+    """BASELINE.json configs[4]: 512 conditionings sharded over 8 ranks (64 per rank and step) -- the job equals the reference's
+    eight-chunk job array (generate.py:204 batch striping, :304 seed + 1000 * chunk), every image exactly once, and the key table
+    built on rank 0 arrives bit-equal on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    recs, hashes = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len({h for pair in hashes for h in pair}) == 1, hashes
+    ref = sum((_single8(c) for c in range(8)), [])
+    ref.sort(key=lambda r: (r["batch_idx"], r["idx"], r["transform"], str(r["param"])))
+    strip = lambda rs: [(r["batch_idx"], r["conditioning"], r["idx"], r["transform"], r["param"], r["metrics"], r["codes"].tolist()) for r in rs]
+    assert strip(recs) == strip(ref)
+    base = [r for r in recs if r["transform"] == "roundtrips" and r["param"] == 0]
+    assert len(base) == 512 and sorted({r["batch_idx"] for r in base}) == list(range(8))
+    assert all(sum(1 for r in base if r["batch_idx"] == b) == 64 for b in range(8))

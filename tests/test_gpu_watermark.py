@@ -193,3 +193,31 @@ def test_process_logits_empty_past_is_a_no_op(kat):
     wm = _wm(kat["keys"]["rar"], seed="linear", h=2)
     one = torch.zeros(3, 1, dtype=torch.int64, device="cuda")
     assert torch.equal(wm.spawn_logit_processor()(past_ids=one, logits=lg.clone()), lg)
+
+
+def test_linear_context_16_small_vocabulary_against_the_oracle():
+    """LINEAR seeding at the largest context size the build takes (WMAR_MAX_CONTEXT 16; the reference takes any,
+    gentime_watermark.py:236-241) on a 512-entry vocabulary (8177 key rows): logit processor incl. rows whose context is too short,
+    detector counts / p-values / masks, token for token against the oracle."""
+    from oracle import wm_oracle as W
+    from wmar_amd.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
+    V, h = 512, 16
+    alive = list(range(0, V, 2)) + list(range(1, V, 4))
+    dead = sorted(set(range(V)) - set(alive))
+    vq = {"alive_ids": torch.tensor(alive), "dead_ids": torch.tensor(dead), "embedding": None}
+    wm = GentimeWatermark(vq, V, SeedStrategy.LINEAR, SplitStrategy.RANDOM_STRATIFIED, h, 1.5, 0.25, device="cuda")
+    key = W.KeyParams(alive, dead, V, 0.25, split="stratifiedrand", seed="linear", context_size=h)
+    assert wm.key_table().shape[0] == h * (V - 1) + 1 and wm.key_table_bytes == wm.key_table().numel() * 4
+    rs = np.random.RandomState(16)
+    logits = rs.randn(6, V).astype(np.float32)
+    for t in (3, 16, 40):                      # shorter than the context (rows skipped), exactly h, longer
+        past = rs.randint(0, V, size=(6, t)).astype(np.int64)
+        got = wm._process_logits(torch.from_numpy(past).cuda(), torch.from_numpy(logits).clone().cuda()).cpu().numpy()
+        assert np.array_equal(got, W.process_logits(key, past, logits, 1.5)), t
+    codes = rs.randint(0, V, size=(5, 256)).astype(np.int64)
+    codes[1, 100:140] = codes[1, 40:80]        # repeated n-grams are scored once
+    pv, ns, ng, masks = wm.detect_counts(torch.from_numpy(codes).cuda(), return_masks=True)
+    rpv, rns, rng, rmasks = W.detect(key, codes, return_masks=True)
+    assert np.array_equal(ns.cpu().numpy(), rns) and np.array_equal(ng.cpu().numpy(), rng)
+    assert np.abs(np.log10(pv.cpu().numpy()) - np.log10(rpv)).max() < 1e-9
+    assert [m[:len(r)] for m, r in zip(masks.cpu().tolist(), rmasks)] == rmasks

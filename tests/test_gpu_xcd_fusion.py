@@ -74,11 +74,12 @@ def test_status_entry_point_and_phase_reset():
         eng.decode_step(tok, t)
     _lib.check(eng._L.wmar_gpt_check(eng._h, _lib.stream_ptr(eng.device)))        # no timeout, no foreign XCD
     # (-1, -1) returns the attention schedule to the automatic one after a manual setting
-    auto = eng.plan_info(8)["attn"]
+    # (16 rows: the automatic schedule of the matrix-core plan is batch-dependent; 1..8 rows run the streaming plan, one attention kernel)
+    auto = eng.plan_info(16)["attn"]
     eng.set_attention_phases(0, 0)
-    assert eng.plan_info(8)["attn"] != auto
+    assert eng.plan_info(16)["attn"] != auto
     eng.set_attention_phases(-1, -1)
-    assert eng.plan_info(8)["attn"] == auto
+    assert eng.plan_info(16)["attn"] == auto
 
 
 _CHILD_FALLBACK = r"""

@@ -173,3 +173,18 @@ def test_checkpoint_loader_roundtrip(tmp_path):
     torch.save({"state_dict": sd, "callbacks": {}}, tmp_path / "checkpoints" / "net2net.ckpt")
     back = tw._tolerant_torch_load(str(tmp_path / "checkpoints" / "net2net.ckpt"))["state_dict"]
     assert set(back) == set(sd)
+
+
+def test_key_table_budget_is_enforced_with_the_numbers(monkeypatch):
+    """A key whose table would not fit the budget is refused at construction, not at the first allocation (8 GiB for LINEAR h = 16
+    over 65536 entries); WMAR_MAX_KEY_TABLE_GB moves the budget."""
+    from wmar_amd.watermarking.gentime_watermark import GentimeWatermark, SeedStrategy, SplitStrategy
+    vq = {"alive_ids": torch.arange(65536), "dead_ids": torch.zeros(0, dtype=torch.long), "embedding": None}
+    with pytest.raises(NotImplementedError, match="8.0 GiB"):
+        GentimeWatermark(vq, 65536, SeedStrategy.LINEAR, SplitStrategy.RANDOM_STRATIFIED, 16, 2.0, 0.25)
+    wm = GentimeWatermark(vq, 65536, SeedStrategy.LINEAR, SplitStrategy.RANDOM_STRATIFIED, 3, 2.0, 0.25)
+    assert wm.key_table_bytes == (3 * 65535 + 1) * 2048 * 4
+    monkeypatch.setenv("WMAR_MAX_KEY_TABLE_GB", "1")
+    with pytest.raises(NotImplementedError):
+        GentimeWatermark(vq, 65536, SeedStrategy.LINEAR, SplitStrategy.RANDOM_STRATIFIED, 3, 2.0, 0.25)
+    assert GentimeWatermark(vq, 65536, SeedStrategy.FIXED, SplitStrategy.RANDOM_STRATIFIED, 0, 2.0, 0.25).key_table_bytes == 2048 * 4

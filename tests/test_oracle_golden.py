@@ -149,6 +149,22 @@ def test_sampling_loop_tokens(golden, kat, key_factory, tag):
     assert np.array_equal(toks.numpy(), golden[f"loop_{tag}_tokens"])
 
 
+def test_sampling_loop_static_cache_equals_the_cat_form(golden, kat, key_factory):
+    """model_oracle's preallocated-cache form (used by the full-size end-to-end GPU test) against the reference's own
+    tokens, and its logits against the torch.cat form step by step."""
+    tk, tp, T = LOOPS["wm"] if "wm" in LOOPS else list(LOOPS.values())[0]
+    tag = "wm" if "wm" in LOOPS else list(LOOPS)[0]
+    key = key_factory(kat["keys"]["taming"])
+    sd = synth.synth_gpt_state(SMALL_GPT, seed=3, logit_scale=40.0)
+    ra, rb = [], []
+    torch.manual_seed(11)
+    a = M.sample_with_past(sd, SMALL_GPT.n_head, torch.from_numpy(golden["loop_cond"]), 16, T, tk, tp, key, 2.0, record=ra)
+    torch.manual_seed(11)
+    b = M.sample_with_past(sd, SMALL_GPT.n_head, torch.from_numpy(golden["loop_cond"]), 16, T, tk, tp, key, 2.0, record=rb, static_cache=True)
+    assert np.array_equal(b.numpy(), golden[f"loop_{tag}_tokens"]) and np.array_equal(a.numpy(), b.numpy())
+    assert max(float(np.abs(x["logits"] - y["logits"]).max()) for x, y in zip(ra, rb)) < 1e-5
+
+
 def test_sampling_loop_unwatermarked(golden):
     sd = synth.synth_gpt_state(SMALL_GPT, seed=3, logit_scale=40.0)
     torch.manual_seed(11)

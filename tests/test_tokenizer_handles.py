@@ -80,3 +80,20 @@ def test_load_state_dict_rules():
     assert h.quantize.n_e == h.quantize.num_embeddings == 16 and h.quantize.e_dim == 2
     assert h.quantize.embedding.weight is state["quantize.embedding.weight"]
     assert hasattr(h, "quant_conv") and list(h.post_quant_conv.state_dict()) == ["weight", "bias"]
+
+
+def test_load_state_dict_updates_in_place_like_nn_module():
+    """tensors taken before a load keep aliasing the weights (nn.Module.load_state_dict copies into the parameters): state_dict()
+    values, parameters(), a codebook a watermarker holds"""
+    import torch
+    from wmar_amd.models.tokenizer_handles import ModuleHandle
+    state = {"decoder.conv.weight": torch.zeros(2, 3), "decoder.conv.bias": torch.zeros(2), "quantize.embedding.weight": torch.zeros(4, 2)}
+    calls = []
+    h = ModuleHandle(state, "decoder.", lambda: calls.append(1))
+    before = h.state_dict()["conv.weight"]
+    held = next(iter(h.parameters()))
+    h.load_state_dict({"conv.weight": torch.ones(2, 3), "conv.bias": torch.full((2,), 2.0)})
+    assert calls == [1]
+    assert torch.equal(before, torch.ones(2, 3)) and before.data_ptr() == state["decoder.conv.weight"].data_ptr()
+    assert torch.equal(held, torch.ones(2, 3))
+    assert torch.equal(state["decoder.conv.bias"], torch.full((2,), 2.0)) and torch.equal(state["quantize.embedding.weight"], torch.zeros(4, 2))

@@ -23,6 +23,8 @@ SYMBOLS = [
     "wmar_mvq_encode", "wmar_gumbel_key_build", "wmar_gumbel_sample", "wmar_gumbel_score", "wmar_rar_generate_gumbel", "wmar_rar_check", "wmar_rar_launch_status",
     "wmar_cham_create", "wmar_cham_destroy", "wmar_cham_device_bytes", "wmar_cham_forward_tokens", "wmar_cham_generate_image",
     "wmar_cham_sample",
+    "wmar_augment",
+    "wmar_comm_unique_id", "wmar_comm_init", "wmar_comm_bcast", "wmar_comm_allgather", "wmar_comm_rank", "wmar_comm_world", "wmar_comm_destroy",
 ]
 
 WMAR_ESHORT = -3
@@ -117,6 +119,17 @@ def load():
     L.wmar_detect.argtypes = [C.POINTER(WmCtx), f64, vp, i64, i64, vp, vp, vp, vp, i64, vp]
     L.wmar_detect_num_ngrams.restype = i64
     L.wmar_detect_num_ngrams.argtypes = [i32, i32, i64]
+    L.wmar_augment.argtypes = [i32, vp, vp, vp, i64, i32, i32, i32, i32, f64, f64, vp]
+    L.wmar_comm_unique_id.argtypes = [vp, i64]
+    L.wmar_comm_init.argtypes = [vp, i64, i32, i32, C.POINTER(vp)]
+    L.wmar_comm_bcast.argtypes = [vp, vp, i64, i32, vp]
+    L.wmar_comm_allgather.argtypes = [vp, vp, vp, i64, vp]
+    L.wmar_comm_rank.argtypes = [vp]
+    L.wmar_comm_rank.restype = i32
+    L.wmar_comm_world.argtypes = [vp]
+    L.wmar_comm_world.restype = i32
+    L.wmar_comm_destroy.argtypes = [vp]
+    L.wmar_comm_destroy.restype = None
     L.wmar_gpt_create.argtypes = [C.POINTER(GptConfig), C.POINTER(C.c_char_p), C.POINTER(vp), i32, vp, C.POINTER(vp)]
     L.wmar_gpt_destroy.argtypes = [vp]
     L.wmar_gpt_destroy.restype = None

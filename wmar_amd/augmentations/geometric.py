@@ -14,6 +14,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as TF
 
+from . import device_ops as _dev
+
 
 def rotate_nearest(image: torch.Tensor, angle: float) -> torch.Tensor:
     """Counter-clockwise rotation by ``angle`` degrees about the image centre: nearest interpolation, same canvas, zero fill
@@ -57,6 +59,8 @@ class Identity(_Named):
 
 class HorizontalFlip(_Named):
     def forward(self, image, *args, **kwargs):
+        if _dev.eligible(image):
+            return _dev.run(_dev.FLIP_H, image)
         return image.flip(-1)
 
 
@@ -79,6 +83,8 @@ class Rotate(_Named):
     def forward(self, image, angle=None):
         angle = self.get_random_angle() if angle is None else angle
         quarters, rest = divmod(angle, 90)          # floor division: -20 -> (-1, 70)
+        if _dev.eligible(image) and (quarters % 2 == 0 or image.shape[-1] == image.shape[-2]):
+            return image if angle % 360 == 0 else _dev.run(_dev.ROTATE, image, quarters % 4, rest)      # MI355X: one launch, both steps
         if quarters % 4:
             image = torch.rot90(image, quarters % 4, dims=(-2, -1))
         return rotate_nearest(image, rest)
@@ -108,6 +114,9 @@ class UpperLeftCropWithResizeBack(_Named):
 
     def forward(self, image, crop_size=None):
         full = tuple(image.shape[-2:])
+        if _dev.eligible(image) and crop_size is not None:
+            oh, ow = int(crop_size * full[0]), int(crop_size * full[1])
+            return image if (oh, ow) == full else _dev.run(_dev.CROP_RESIZE, image, oh, ow)
         part = self.crop(image, crop_size)
         return part if tuple(part.shape[-2:]) == full else resize_bilinear(part, full)
 
@@ -119,6 +128,8 @@ class UpperLeftCropWithPadBack(_Named):
 
     def forward(self, image, crop_size=None):
         full_h = image.shape[-2]
+        if _dev.eligible(image) and crop_size is not None and image.shape[-1] == full_h:
+            return _dev.run(_dev.CROP_PAD, image, int(crop_size * full_h), int(crop_size * full_h))
         part = self.crop(image, crop_size)
         missing = full_h - part.shape[-2]
         return TF.pad(part, (0, missing, 0, missing), mode="constant", value=0.0)      # right and bottom, as F.pad(img, (0, 0, p, p))

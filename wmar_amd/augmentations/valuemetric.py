@@ -16,6 +16,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as TF
 
+from . import device_ops as _dev
+
 
 # ------------------------------------------------------------------ functional forms
 def _gaussian_kernel1d(kernel_size: int, sigma: float, dtype, device) -> torch.Tensor:
@@ -117,7 +119,10 @@ class GaussianBlur(_Ranged):
     def forward(self, image, kernel_size=None):
         if kernel_size == 0:                    # the sweep's "no blur" entry
             return image
-        return gaussian_blur(image, kernel_size or self.get_random_kernel_size()).clamp(0, 1)
+        k = kernel_size or self.get_random_kernel_size()
+        if _dev.eligible(image):                # MI355X: one launch over the batch (csrc/augment.hip), clamp inside
+            return _dev.run(_dev.BLUR, image, k)
+        return gaussian_blur(image, k).clamp(0, 1)
 
 
 class Brightness(_Ranged):
@@ -129,7 +134,10 @@ class Brightness(_Ranged):
     get_random_factor = _Ranged._uniform
 
     def forward(self, image, factor=None):
-        return adjust_brightness(image, self.get_random_factor() if factor is None else factor)
+        factor = self.get_random_factor() if factor is None else factor
+        if _dev.eligible(image):
+            return _dev.run(_dev.BRIGHTNESS, image, factor)
+        return adjust_brightness(image, factor)
 
 
 class GaussianNoise(_Ranged):
@@ -141,4 +149,7 @@ class GaussianNoise(_Ranged):
     get_random_std = _Ranged._uniform
 
     def forward(self, image, std=None):
-        return add_gaussian_noise(image, self.get_random_std() if std is None else std).clamp(0, 1)
+        std = self.get_random_std() if std is None else std
+        if _dev.eligible(image):                # the draws stay torch.randn_like (the reference's RNG call); the arithmetic is the kernel's
+            return _dev.run(_dev.NOISE, image, std, noise=torch.randn_like(image))
+        return add_gaussian_noise(image, std).clamp(0, 1)

@@ -15,12 +15,14 @@ LIB = os.path.join(HERE, "libwmar_hip.so")
 # (include/wmar_math.h): no fp contraction there.
 SOURCES = [
     ("keytable.cpp", []),
+    ("comm.cpp", []),
     ("watermark.hip", ["-ffp-contract=off"]),
     ("gumbel.hip", ["-ffp-contract=off"]),
     ("gpt.hip", []),
     ("rar.hip", []),
     ("cham.hip", []),
     ("vqgan.hip", []),
+    ("augment.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-Wno-unused-variable", "-x", "hip"]

@@ -799,8 +799,11 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
         if (tmp) (void)hipFree(tmp);
         // ... and every workgroup of its grid must be resident at once: one per CU at least (a CU mask or a partition mode shrinks
         // what the runtime reports)
+        // (the instantiation that will run: WMAR_XR_NW4=1 selects the four-wave variant, another register / LDS footprint)
         int nb = 0, dev = 0, cus = 0;
-        if (ok) ok = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bx_xr<BX_PER / 2, 4, 8>, 512, 0) == hipSuccess && hipGetDevice(&dev) == hipSuccess &&
+        const bool xr4 = getenv("WMAR_XR_NW4") != nullptr;
+        if (ok) ok = (xr4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bx_xr<BX_PER, 4>, 256, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_bx_xr<BX_PER / 2, 4, 8>, 512, 0)) == hipSuccess && hipGetDevice(&dev) == hipSuccess &&
                      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
                      (long long)nb * cus >= (long long)(D / 32) * 4;
         g->xcd_ok = ok;
@@ -827,6 +830,8 @@ static int gpt_sync_failed(wmar_gpt* g, hipStream_t st) {
     WMAR_HIP_CHECK(hipMemsetAsync(g->xsync, 0, (8 * 64 + 64) * 4, st));
     g->xcd_ok = false;                  // the two-launch path from here on
     g->fallbacks += 1;
+    fprintf(stderr, "wmar_amd: the fused projection launch (k_bx_xr) %s; this engine continues on the two-launch path (the call is re-run; "
+                    "wmar_gpt_plan_info reports barrier_fallbacks)\n", f[0] ? "found a workgroup on a foreign XCD" : "gave up waiting at its XCD-local barrier");
     return 1;
 }
 // tests: raise the timeout flag in front of the next fused call, once

@@ -863,12 +863,16 @@ void wmar_rar_destroy(wmar_rar* g) { delete g; }
 // The in-launch waits of k_resid_mod raise g->sync_fail when they give up.  Returns 1 when the flag was up: the engine has then been
 // switched to the two-launch pair, its graph dropped and the flag cleared -- the caller repeats its work (deterministic in its
 // inputs).  0: clean.  < 0: HIP error.
-static int rar_sync_failed(wmar_rar* g, hipStream_t st) {
-    if (!g->rm_fused) return 0;
+// `always`: read the flag on the two-launch pair as well (wmar_rar_check, which the Python engine calls behind every generation): there
+// the second launch raises it when it reads a still-poisoned partial sum, i.e. an ORDERING bug of the pair -- nothing to fall back to,
+// returns 2.  The generation loops themselves pass false and stay asynchronous on the pair.
+static int rar_sync_failed(wmar_rar* g, hipStream_t st, bool always = false) {
+    if (!g->rm_fused && !always) return 0;
     unsigned f = 0;
     WMAR_HIP_CHECK(hipMemcpyAsync(&f, g->sync_fail, 4, hipMemcpyDeviceToHost, st));
     WMAR_HIP_CHECK(hipStreamSynchronize(st));
     if (!f) return 0;
+    if (!g->rm_fused) { WMAR_HIP_CHECK(hipMemsetAsync(g->sync_fail, 0, 4, st)); return 2; }
     g->drop_graph();
     WMAR_HIP_CHECK(hipMemsetAsync(g->sync_fail, 0, 4, st));
     g->rm_fused = false;
@@ -884,8 +888,13 @@ static int rar_inject(wmar_rar* g, hipStream_t st) {
 int wmar_rar_check(wmar_rar* g, void* stream) {
     WMAR_REQUIRE(g, "rar_check: null argument");
     // generate / forward_position verify and recover by themselves; kept for callers that want to know whether the fused launch still runs
-    const int f = rar_sync_failed(g, (hipStream_t)stream);
+    const int f = rar_sync_failed(g, (hipStream_t)stream, true);
     if (f < 0) return f;
+    if (f == 2) {
+        set_error("rar: the second launch of the two-launch residual pair read a partial sum its first launch had not written (poisoned "
+                  "word): the launches since the last check are invalid");
+        return WMAR_EHIP;
+    }
     if (f > 0) {
         set_error("rar: an in-launch wait of k_resid_mod gave up (its workgroups were not co-resident): the launches since the last check "
                   "are invalid (the engine continues on the two-launch pair)");

@@ -57,11 +57,19 @@ def fill_batch_log(batch_log, key, model, codes, eval_params, sync_manager=None)
         curr_codes = model.images_to_codes(curr_imgs)
         curr_imgs = model.codes_to_images(curr_codes)
         batch_log[key]["roundtrips"].append((T, curr_codes.cpu().numpy(), curr_imgs.cpu().numpy(), None))
+    from .augmentations import device_ops as _dev_aug
+    # the fused form is the default table's arithmetic: only for the AugmentationManager's own entries (a caller's own callable under
+    # one of its names keeps its callable)
+    fused_ok = eval_params.get("fuse_augmentations", True)
     for aug_name, aug_fn, aug_params in eval_params.get("augmentations", []):
         batch_log[key][aug_name] = []
         for aug_param in aug_params:
-            imgs_zero_to_one = imgs / 2.0 + 0.5
-            aug_imgs = aug_fn(imgs_zero_to_one, aug_param).clamp(0, 1) * 2.0 - 1.0
+            # one launch per (transform, parameter) over the whole batch where the transform has a device form (csrc/augment.hip:
+            # range change, transform, clamp and range change back fused; bit-identical to the sequence below), else the module
+            aug_imgs = _dev_aug.fused(aug_name, imgs, aug_param) if fused_ok else None
+            if aug_imgs is None:
+                imgs_zero_to_one = imgs / 2.0 + 0.5
+                aug_imgs = aug_fn(imgs_zero_to_one, aug_param).clamp(0, 1) * 2.0 - 1.0
             aug_codes = model.images_to_codes(aug_imgs)
             batch_log[key][aug_name].append((aug_param, aug_codes.cpu().numpy(), aug_imgs.cpu().numpy(), None))
 
@@ -177,9 +185,18 @@ def gather_records(recs, eval_params, device, dst=0):
     index = {(t, str(p)): i for i, (t, p) in enumerate(combos)}
     n = len(recs)
     L = max([len(r["codes"]) for r in recs], default=0)
+    from . import comm as _comm
+    rc = _comm.active(device)           # WMAR_COMM=rccl: the C-ABI RCCL wrappers instead of torch.distributed (same exchange)
+
+    def _all_gather(t):
+        if rc is not None:
+            return rc.all_gather(t)
+        outs = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        return outs
+
     meta = torch.tensor([n, L], dtype=torch.int64, device=device)
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta)
+    metas = _all_gather(meta)
     n_max = max(int(m[0]) for m in metas)
     L_max = max(int(m[1]) for m in metas)
     rows = torch.zeros(n_max, _REC_COLS, dtype=torch.float64)
@@ -194,10 +211,8 @@ def gather_records(recs, eval_params, device, dst=0):
                                 r["sample_seconds"], bits], dtype=torch.float64)
         codes[i, :len(r["codes"])] = torch.from_numpy(r["codes"])
     rows, codes = rows.to(device), codes.to(device)
-    all_rows = [torch.zeros_like(rows) for _ in range(world)]
-    all_codes = [torch.zeros_like(codes) for _ in range(world)]
-    dist.all_gather(all_rows, rows)
-    dist.all_gather(all_codes, codes)
+    all_rows = _all_gather(rows)
+    all_codes = _all_gather(codes)
     if rank != dst:
         return None
     method = recs[0]["method"] if recs else None
@@ -246,13 +261,19 @@ def broadcast_key_table(watermarker, device, src=0):
     import torch.distributed as dist
 
     if dist.get_rank() == src:
-        table = watermarker.key_table()
+        # the builder is host code either way; on a CPU process group (gloo: the N > 1 tests) the finished bitmap stays on the host
+        on_gpu = torch.device(device).type == "cuda"
+        host_build = not on_gpu and hasattr(watermarker, "key_table_host")
+        table = torch.from_numpy(watermarker.key_table_host().view(np.int32).copy()) if host_build else watermarker.key_table()
         shape = torch.tensor(list(table.shape), dtype=torch.int64, device=device)
     else:
         shape = torch.zeros(2, dtype=torch.int64, device=device)
-    dist.broadcast(shape, src)
+    from . import comm as _comm
+    rc = _comm.active(device)
+    bcast = (lambda t: rc.broadcast_(t, src)) if rc is not None else (lambda t: dist.broadcast(t, src))
+    bcast(shape)
     if dist.get_rank() != src:
         table = torch.empty(tuple(shape.tolist()), dtype=torch.int32, device=device)
-    dist.broadcast(table, src)
+    bcast(table)
     watermarker.set_key_table(table)
     return table

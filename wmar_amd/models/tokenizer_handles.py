@@ -45,8 +45,11 @@ class ModuleHandle:
             raise RuntimeError("Error(s) in loading state_dict for {}:\n\t{}".format(type(self).__name__, "\n\t".join(errors)))
         for k in own:
             if k[n:] in state_dict:
+                # in place, as nn.Module.load_state_dict does (param.copy_): tensors taken earlier -- state_dict() values,
+                # parameters(), a codebook a watermarker holds -- keep aliasing the updated weights
                 cur = self._state[k]
-                self._state[k] = state_dict[k[n:]].detach().to(device=cur.device, dtype=cur.dtype).clone()
+                with torch.no_grad():
+                    cur.copy_(state_dict[k[n:]].detach().to(device=cur.device, dtype=cur.dtype))
         self._on_change()
         return IncompatibleKeys(missing, unexpected)
 

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import collections
+import os
 import hashlib
 from enum import Enum
 from functools import partial
@@ -108,6 +109,17 @@ class GentimeWatermark:
             raise AssertionError("Spatial seeding only implemented for context size in [1,3]")
         if not 0 <= context_size <= MAX_CONTEXT:
             raise NotImplementedError(f"context sizes 0..{MAX_CONTEXT} are supported (the key table has context_size * (vocab - 1) + 1 rows)")
+        # The key is a table of one greenlist bitmap per context SUM: context_size * (vocab - 1) + 1 rows of vocab / 8 bytes, built
+        # eagerly on the host and kept in HBM -- 32 MiB for Taming h = 1, 0.5 GiB at h = 16, 8.6 GiB for a 65536-entry vocabulary at
+        # h = 16.  Refuse a key beyond the budget here, with the numbers, instead of at the first allocation.
+        rows = 1 if seed_strategy is SeedStrategy.FIXED else context_size * (int(vocab_size) - 1) + 1
+        self.key_table_bytes = rows * ((int(vocab_size) + 31) // 32) * 4
+        budget = float(os.environ.get("WMAR_MAX_KEY_TABLE_GB", "4")) * (1 << 30)
+        if self.key_table_bytes > budget:
+            raise NotImplementedError(
+                f"the key table of {seed_strategy.value} seeding with context_size {context_size} over a vocabulary of {vocab_size} has {rows} rows "
+                f"= {self.key_table_bytes / (1 << 30):.1f} GiB, above the budget of {budget / (1 << 30):.1f} GiB (WMAR_MAX_KEY_TABLE_GB); "
+                f"use a smaller context_size")
         self._table = None
         if self.seed_strategy == SeedStrategy.FIXED:
             self.fixed_greenlist = self._split_with_seed(0)
