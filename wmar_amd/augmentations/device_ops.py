@@ -4,6 +4,8 @@ for tensors on the MI355X, and the harness's fused form -- one launch that reads
 image).  CPU tensors keep the torch restatements in valuemetric.py / geometric.py (host-side utilities, as in the reference)."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import _lib
@@ -12,6 +14,8 @@ IDENTITY, BLUR, NOISE, BRIGHTNESS, ROTATE, FLIP_H, CROP_RESIZE, CROP_PAD = range
 
 
 def eligible(image: torch.Tensor) -> bool:
+    if os.environ.get("WMAR_AUG_TORCH"):        # A/B knob: the torch restatements on the device instead of the kernels
+        return False
     return image.is_cuda and image.dtype == torch.float32 and image.dim() in (3, 4)
 
 
