@@ -91,3 +91,43 @@ def test_batch_5_watermarked_loop_equals_matrix_core_plan(kat, gpt, gpt_mfma, gr
         assert bad.size == 0, f"row {r} diverges at step {n}"
     pa, pb = wm.detect(torch.from_numpy(a).cuda()).cpu().numpy(), wm.detect(torch.from_numpy(b).cuda()).cpu().numpy()
     assert np.array_equal(pa, pb)
+
+
+@pytest.fixture(scope="module")
+def gpt_persist():
+    """the opt-in persistent step (wmar_amd/csrc/decode_persist.h: one launch per decode step, device-wide barriers between its
+    phases; measured slower than the five-launch plan and therefore not the default -- DESIGN section 6a)"""
+    from wmar_amd.models.engine import GPTEngine
+    os.environ["WMAR_PERSIST"] = "1"
+    try:
+        return GPTEngine(GCFG, synth.synth_gpt_state(GCFG, seed=9, logit_scale=10.0), max_batch=8)
+    finally:
+        del os.environ["WMAR_PERSIST"]
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 5])
+def test_persistent_step_matches_the_reference_fixture_and_the_launch_plan(pv, kat, gpt, gpt_persist, B):
+    info = gpt_persist.plan_info(B)
+    if "persistent" not in info.get("path", ""):
+        pytest.skip("the persistent step is not available on this device (workgroups not co-resident / XCD grouping): " + info.get("path", ""))
+    assert "persistent" not in gpt.plan_info(B).get("path", "") and "k_sgemv" in gpt_persist.plan_info(6)["qkv"]
+    seq = torch.from_numpy(pv["gpt_seq"].astype(np.int64))[:B].cuda()
+    want = {int(p): i for i, p in enumerate(pv["gpt_pos"])}
+    worst = 0.0
+    for t in range(256):
+        lg = gpt_persist.decode_step(seq[:, t], t)
+        assert np.array_equal(lg.argmax(-1).cpu().numpy(), pv["gpt_argmax"][t].astype(np.int64)[:B]), t
+        if t in want:
+            d = float(np.abs(lg[:, ::64].cpu().numpy() - pv["gpt_logits"][want[t]][:B]).max())
+            worst = max(worst, d)
+            assert d < ATOL, (B, t, d)
+    # the captured 256-step loop: same tokens as the five-launch plan on the same noise
+    wm = _wm(kat["keys"]["taming"])
+    g = torch.Generator(device="cuda").manual_seed(77 + B)
+    q = torch.empty(256, B, 16384, device="cuda").exponential_(1, generator=g)
+    cond = torch.tensor([1, 9, 232, 340, 568][:B]).cuda()
+    a = gpt_persist.generate(cond, 256, q, 1.0, 250, 0.92, wm.wm_ctx(), use_graph=True)
+    b = gpt.generate(cond, 256, q, 1.0, 250, 0.92, wm.wm_ctx(), use_graph=True)
+    assert torch.equal(a, b)
+    assert gpt_persist.plan_info(B)["barrier_fallbacks"] == "0"
+    print(f"persistent step, {B} rows: max |dlogit| {worst:.2e} over {len(want)} positions; 256-step loop equal to the launch plan")

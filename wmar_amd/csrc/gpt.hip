@@ -23,6 +23,7 @@
 
 #include "decoder_host.h"
 #include "decode_small.h"
+#include "decode_persist.h"
 
 
 using namespace wmar;
@@ -39,7 +40,7 @@ struct LayerW {
 
 // Row-major weights of the small-batch path (decode_small.h): the checkpoint's own layout, LayerNorm NOT folded.
 struct SmallW {
-    float *wqkv = nullptr, *bqkv = nullptr, *wproj = nullptr, *wfc1 = nullptr, *bfc1 = nullptr, *wfc2 = nullptr;
+    float *wqkv = nullptr, *bqkv = nullptr, *wproj = nullptr, *bproj = nullptr, *wfc1 = nullptr, *bfc1 = nullptr, *wfc2 = nullptr, *bfc2 = nullptr;
     float *ln1w = nullptr, *ln1b = nullptr, *ln2w = nullptr, *ln2b = nullptr;
 };
 
@@ -54,6 +55,12 @@ struct wmar_gpt {
     float *whead_rm = nullptr, *lnfw = nullptr, *lnfb = nullptr;
     float *xs = nullptr, *ys = nullptr, *hs = nullptr, *qs = nullptr;     // [8][D], [8][D], [8][4D], [8][D] row-major
     bool small_ok = false;
+    // ... and for 1..5 rows the whole step as ONE persistent launch (decode_persist.h): needs all 256 workgroups resident and the
+    // blockIdx % 8 -> XCD grouping; a barrier that gives up switches the engine back to the five-launch plan (the call is re-run)
+    float* sw_arena = nullptr;         // all layers' small-batch weights, SS_LAYER_FLOATS per layer (SmallW points into it)
+    unsigned* ss_bar = nullptr;        // barrier words + fail flag (SS_BAR_WORDS)
+    bool persist_ok = false;
+    bool ps_enqueued = false;          // a persistent launch was enqueued since the last flag check
     bool xr_enqueued = false;      // a fused projection launch (k_bx_xr) was enqueued since the last flag check
     float *tok_emb = nullptr, *pos_emb = nullptr, *bhead = nullptr, *chead = nullptr;
     float4* whead = nullptr;
@@ -214,9 +221,11 @@ struct StepPlan {
     bool proj_xr = false;     // ... with the residual fold + LN2 statistics inside the launch (k_bx_xr): no k_resid_stats behind it
     int nch_ln2 = 0;          // statistics chunks the FC1 launch reads (16 = two per XCD group behind k_bx_xr)
     bool small = false;       // 1..8 rows on an eligible engine: the streaming path of decode_small.h
+    bool persist = false;     // 1..5 rows: the whole step as one persistent launch (decode_persist.h)
 
     StepPlan(wmar_gpt* g_, int64_t B_, const StepIO& io_, hipStream_t st_) : g(g_), B(B_), io(io_), st(st_) {
         small = B <= SG_MAX_ROWS && g->small_ok;
+        persist = small && B <= SS_MAX_ROWS && g->persist_ok;
         MT = mt_for(B); D = g->D; KBD = D / 8; KBF = 4 * D / 8; nch = stat_chunks(KBD);
         act = (long long)KBD * MT * 64;  // float4 units of one [M][D] packed activation
         r.x = g->x; r.stats = g->stats; r.KB = KBD; r.MT = MT; r.n_chunks = nch;
@@ -534,6 +543,19 @@ int enqueue_step(wmar_gpt* g, int64_t B, const StepIO& io, hipStream_t st) {
 #ifdef WMAR_DEV_KNOBS
     if (g->dbg_sums) { g->dbg_slot = 0; if (hipMemsetAsync(g->dbg_sums, 0, 4096 * 8, st) != hipSuccess) return WMAR_EHIP; }
 #endif
+    if (p.persist) {
+        SsArgs a{};
+        a.arena = g->sw_arena; a.L = g->L; a.tok_emb = g->tok_emb; a.pos_emb = g->pos_emb; a.whead = g->whead_rm; a.lnfw = g->lnfw; a.lnfb = g->lnfb;
+        a.tok = io.tok; a.tok_stride = io.tok_stride; a.tok_use_pos = io.tok_use_pos;
+        a.xs = g->xs; a.ys = g->ys; a.hs = g->hs; a.qs = g->qs; a.kcache = g->kcache; a.vcache = g->vcache;
+        a.lstride = (long long)g->Bmax * g->H * g->Tmax * g->hd; a.logits = io.logits; a.V = g->V; a.pos_dev = g->pos_dev;
+        a.D = g->D; a.H = g->H; a.Tmax = g->Tmax; a.bar = g->ss_bar;
+        g->span_begin(WMAR_T_QKV, st);
+        rc = launch_sstep(a, (int)B, st);
+        g->span_end(st);
+        g->ps_enqueued = true;
+        return rc;
+    }
     if ((rc = p.embed())) return rc;
     if (p.small) {
         // 1..8 rows: five streaming launches per layer, the residual stream updated in place (decode_small.h)
@@ -710,28 +732,26 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
     if (rc == WMAR_OK && D == 2 * SG_SEG && hd == 64 && !getenv("WMAR_NO_SMALL")) {
         g->sw.resize(L);
         const size_t DD = (size_t)D * D;
+        // ONE allocation, fixed per-layer stride (decode_persist.h forms every address from this base)
+        TRY(g->alloc(&g->sw_arena, (size_t)L * SS_LAYER_FLOATS));
         for (int l = 0; l < L && rc == WMAR_OK; ++l) {
             std::string p = "blocks." + std::to_string(l) + ".";
             SmallW& w = g->sw[l];
-            TRY(g->alloc(&w.wqkv, 3 * DD));
-            TRY(g->alloc(&w.bqkv, (size_t)3 * D));
-            if (rc == WMAR_OK) {
-                const char* nm[3] = {"attn.query", "attn.key", "attn.value"};
-                hipError_t e = hipSuccess;
-                for (int i = 0; i < 3 && e == hipSuccess; ++i) {
-                    e = hipMemcpyAsync(w.wqkv + i * DD, tm.get(p + nm[i] + ".weight"), DD * 4, hipMemcpyDeviceToDevice, st);
-                    if (e == hipSuccess) e = hipMemcpyAsync(w.bqkv + (size_t)i * D, tm.get(p + nm[i] + ".bias"), (size_t)D * 4, hipMemcpyDeviceToDevice, st);
-                }
-                if (e != hipSuccess) { set_error("gpt_create: %s", hipGetErrorString(e)); rc = WMAR_EHIP; }
-            }
-            TRY(copy_vec(g, &w.wproj, tm.get(p + "attn.proj.weight"), DD, st));
-            TRY(copy_vec(g, &w.wfc1, tm.get(p + "mlp.0.weight"), 4 * DD, st));
-            TRY(copy_vec(g, &w.bfc1, tm.get(p + "mlp.0.bias"), (size_t)4 * D, st));
-            TRY(copy_vec(g, &w.wfc2, tm.get(p + "mlp.2.weight"), 4 * DD, st));
-            TRY(copy_vec(g, &w.ln1w, tm.get(p + "ln1.weight"), D, st));
-            TRY(copy_vec(g, &w.ln1b, tm.get(p + "ln1.bias"), D, st));
-            TRY(copy_vec(g, &w.ln2w, tm.get(p + "ln2.weight"), D, st));
-            TRY(copy_vec(g, &w.ln2b, tm.get(p + "ln2.bias"), D, st));
+            float* base = g->sw_arena + (size_t)l * SS_LAYER_FLOATS;
+            w.wqkv = base + SS_OFF_WQKV; w.wproj = base + SS_OFF_WPROJ; w.wfc1 = base + SS_OFF_WFC1; w.wfc2 = base + SS_OFF_WFC2;
+            w.bqkv = base + SS_OFF_BQKV; w.bproj = base + SS_OFF_BPROJ; w.bfc1 = base + SS_OFF_BFC1; w.bfc2 = base + SS_OFF_BFC2;
+            w.ln1w = base + SS_OFF_LN1W; w.ln1b = base + SS_OFF_LN1B; w.ln2w = base + SS_OFF_LN2W; w.ln2b = base + SS_OFF_LN2B;
+            hipError_t e = hipSuccess;
+            auto cp = [&](float* dst, const std::string& key, size_t n) {
+                if (e == hipSuccess) e = hipMemcpyAsync(dst, tm.get(p + key), n * 4, hipMemcpyDeviceToDevice, st);
+            };
+            cp(w.wqkv, "attn.query.weight", DD); cp(w.wqkv + DD, "attn.key.weight", DD); cp(w.wqkv + 2 * DD, "attn.value.weight", DD);
+            cp(w.bqkv, "attn.query.bias", D); cp(w.bqkv + D, "attn.key.bias", D); cp(w.bqkv + 2 * D, "attn.value.bias", D);
+            cp(w.wproj, "attn.proj.weight", DD); cp(w.bproj, "attn.proj.bias", D);
+            cp(w.wfc1, "mlp.0.weight", 4 * DD); cp(w.bfc1, "mlp.0.bias", (size_t)4 * D);
+            cp(w.wfc2, "mlp.2.weight", 4 * DD); cp(w.bfc2, "mlp.2.bias", D);
+            cp(w.ln1w, "ln1.weight", D); cp(w.ln1b, "ln1.bias", D); cp(w.ln2w, "ln2.weight", D); cp(w.ln2b, "ln2.bias", D);
+            if (e != hipSuccess) { set_error("gpt_create: %s", hipGetErrorString(e)); rc = WMAR_EHIP; }
         }
         TRY(copy_vec(g, &g->whead_rm, hw, (size_t)V * D, st));
         TRY(copy_vec(g, &g->lnfw, lfw, D, st));
@@ -741,6 +761,33 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
         TRY(g->alloc(&g->hs, (size_t)SG_MAX_ROWS * 4 * D));
         TRY(g->alloc(&g->qs, (size_t)SG_MAX_ROWS * D));
         g->small_ok = rc == WMAR_OK;
+        // the persistent step: per-layer pointer table, barrier words; all 256 workgroups of 320 threads must be resident at once and
+        // workgroups with equal blockIdx % 8 must share an XCD (probed below with the kernel's own grid).  WMAR_NO_PERSIST=1: off.
+        static_assert(SSD == 2 * SG_SEG, "arena offsets are for n_embd 1536");
+        // OPT-IN (WMAR_PERSIST=1 at creation): measured SLOWER than the five launches it replaces (round 6, DESIGN section 6a: 2.01 against
+        // 1.63 ms per step at batch 1, 2.85 against 1.89 at batch 5) -- the barrier's atomics and polls travel through the same in-order
+        // per-CU memory pipeline as the weight prefetch they are meant to overlap with; kept as a tested experiment, not the default plan.
+        if (g->small_ok && getenv("WMAR_PERSIST") && !getenv("WMAR_NO_PERSIST")) {
+            TRY(g->alloc(&g->ss_bar, (size_t)SS_BAR_WORDS));
+            if (rc == WMAR_OK && hipMemsetAsync(g->ss_bar, 0, SS_BAR_WORDS * 4, st) != hipSuccess) { set_error("gpt_create: memset failed"); rc = WMAR_EHIP; }
+            if (rc == WMAR_OK) {
+                int dev = 0, cus = 0;
+                bool ok = hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess;
+                ok = ok && (long long)sstep_blocks_per_cu() * cus >= SS_WGS;
+                unsigned* tmp = nullptr;
+                ok = ok && hipMalloc(&tmp, SS_WGS * 4) == hipSuccess;
+                for (int rep = 0; rep < 3 && ok; ++rep) {
+                    unsigned h[SS_WGS];
+                    hipLaunchKernelGGL(k_xcc_probe, dim3(SS_WGS), dim3(SS_THREADS), 0, st, tmp);
+                    ok = hipMemcpyAsync(h, tmp, sizeof h, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+                    unsigned seen = 0;
+                    for (int b = 0; b < SS_WGS && ok; ++b) ok = h[b] == h[b & 7] && h[b] < 16;
+                    for (int x = 0; x < 8 && ok; ++x) { ok = !(seen & (1u << h[x])); seen |= 1u << h[x]; }
+                }
+                if (tmp) (void)hipFree(tmp);
+                g->persist_ok = ok;
+            }
+        }
     }
     const size_t Mpad = (size_t)g->MTmax * 32;
     TRY(g->alloc(&g->x, Mpad * D / 4));
@@ -817,7 +864,25 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
 // The fused projection launch (k_bx_xr) raises device flags when its XCD-local barrier gives up or a block sits on a foreign XCD.
 // Returns 1 when a flag was up: the engine has then been switched to the two-launch path (k_bx + k_resid_stats), its graphs dropped
 // and the flags cleared -- the caller re-runs its work, which is deterministic in its inputs.  0: clean.  < 0: HIP error.
+// the persistent step's barrier (decode_persist.h): 1 when a wait gave up -- the engine is switched to the five-launch plan, its graphs
+// dropped, the barrier words cleared; the caller re-runs its work
+static int gpt_persist_failed(wmar_gpt* g, hipStream_t st) {
+    if (!g->ss_bar || !g->persist_ok || !g->ps_enqueued) return 0;
+    g->ps_enqueued = false;
+    unsigned f = 0;
+    WMAR_HIP_CHECK(hipMemcpyAsync(&f, g->ss_bar + 8 * 64 + 64, 4, hipMemcpyDeviceToHost, st));
+    WMAR_HIP_CHECK(hipStreamSynchronize(st));
+    if (!f) return 0;
+    g->drop_graph();
+    WMAR_HIP_CHECK(hipMemsetAsync(g->ss_bar, 0, SS_BAR_WORDS * 4, st));
+    g->persist_ok = false;
+    g->fallbacks += 1;
+    fprintf(stderr, "wmar_amd: the persistent decode step (k_sstep) gave up waiting at its device-wide barrier; this engine continues on the "
+                    "five-launch small-batch plan (the call is re-run; wmar_gpt_plan_info reports barrier_fallbacks)\n");
+    return 1;
+}
 static int gpt_sync_failed(wmar_gpt* g, hipStream_t st) {
+    if (const int pf = gpt_persist_failed(g, st)) return pf;
     // only a fused launch can raise the flags: calls that enqueued none (two-launch path, WMAR_NO_XR, <= 32 rows, the small-batch
     // path) stay asynchronous and legal inside a caller's stream capture
     if (!g->xsync || !g->xcd_ok || g->no_xr || !g->xr_enqueued) return 0;
@@ -929,6 +994,14 @@ int wmar_gpt_plan_info(wmar_gpt* g, int64_t B, char* buf, int64_t buf_len) {
     WMAR_REQUIRE(B >= 1 && B <= g->Bmax, "plan_info: batch outside 1..%d", g->Bmax);
     StepIO io{g->past, (long long)g->Tmax + 1, 0, g->logits};
     StepPlan p(g, B, io, nullptr);
+    if (p.persist) {
+        const int n = snprintf(buf, (size_t)buf_len,
+                               "qkv=k_sstep phase (the arithmetic of k_sgemv<QKV>, weights streamed across the barriers);attn=k_sstep phase;proj=k_sstep phase;resid=none;"
+                               "resid_launches_per_step=0;fc1=k_sstep phase;fc2=k_sstep phase;head=k_sstep phase;barrier_fallbacks=%d;"
+                               "path=persistent step: one launch, %d device-wide barriers (decode_persist.h)", g->fallbacks, 5 * g->L + 1);
+        WMAR_REQUIRE(n > 0 && n < buf_len, "plan_info: buffer of %lld bytes too small", (long long)buf_len);
+        return WMAR_OK;
+    }
     if (p.small) {
         const int n = snprintf(buf, (size_t)buf_len,
                                "qkv=k_sgemv<QKV> (row-major weight stream, LN1 + bias + cache append inside, %d columns per workgroup);"
@@ -1128,7 +1201,7 @@ static int gpt_generate_once(wmar_gpt* g, const wmar_wm_ctx* wm, const wmar_samp
         if (e == hipSuccess) e = hipEventRecord(g->ev1, st);   // also marks "replays finished" for drop_graph()
         if (e == hipSuccess) { g->pending = true; }
         if (e != hipSuccess) { set_error("graph replay failed: %s", hipGetErrorString(e)); return WMAR_EHIP; }
-        { StepPlan pl(g, B, io, nullptr); if (!pl.small && pl.proj_xr) g->xr_enqueued = true; }   // a replay runs the fused launches of its capture
+        { StepPlan pl(g, B, io, nullptr); if (!pl.small && pl.proj_xr) g->xr_enqueued = true; if (pl.persist) g->ps_enqueued = true; }   // a replay runs the launches of its capture
         // asynchronous: the caller's stream orders everything after the replays
         if (g->timing) WMAR_HIP_CHECK(hipEventSynchronize(g->ev1));
     } else {
