@@ -38,8 +38,8 @@ struct SgArgs {
     const float* W;        // [N][K] row-major (the checkpoint's layout)
     const float* bias;     // [N] or null
     const float* x;        // [rows][K] row-major input rows
-    const float* gamma;    // [K] LayerNorm weight / bias in front of the Linear (QKV, FC1, head)
-    const float* beta;
+    const float* gamma;    // [K] LayerNorm weight in front of the Linear (QKV, FC1, head); `bias` is then b + W beta and
+    const float* c1;       // [N] c1[n] = sum_k W[n][k] gamma[k] (the engine's folded vectors, shared with the matrix-core plan)
     float* out;            // PROJ / FC2: residual stream [rows][N], updated in place; FC1: hidden [rows][N]; HEAD: logits [rows][N]; QKV: q [rows][D]
     float* kcache;         // QKV: this layer's [Bmax][H][Tmax][64]
     float* vcache;
@@ -126,9 +126,10 @@ __global__ __launch_bounds__(ROLE == SG_FC2 ? 512 : 256) void k_sgemv(SgArgs a) 
     const int eb = et / cols_wg, ecol = et - eb * cols_wg;
     const int en = blockIdx.x * cols_wg + ecol;
     const bool eon = ROLE != SG_HEAD && et < cols_wg * NB && en < a.N;
-    float ebias = 0.f, eold = 0.f;
+    float ebias = 0.f, eold = 0.f, ec1 = 0.f;
     if (eon) {
         ebias = a.bias[en];
+        if (LN) ec1 = a.c1[en];
         if (ROLE == SG_PROJ || ROLE == SG_FC2) eold = a.out[(long long)eb * a.N + en];
     }
 
@@ -149,15 +150,16 @@ __global__ __launch_bounds__(ROLE == SG_FC2 ? 512 : 256) void k_sgemv(SgArgs a) 
     // splat over both halves (the multiply-adds are what the vector ALU spends its time on: 4 x rows per 16 weight bytes).
     constexpr int NBP = (NB + 1) / 2;
     f32x2 x2[CH][4][NBP];
-    float mu[NB], rstd[NB];
-    float4 gm[CH], bt[CH];
+    // LayerNorm folded around the dot product (the algebra of the matrix-core plan, k_gemm's LN epilogue):
+    //     LN(x) W^T + b = rstd (sum_k W[n][k] gamma[k] x[k] - mean c1[n]) + (b + W beta)[n],   c1[n] = sum_k W[n][k] gamma[k]
+    // so the multiply-adds start on gamma * x the moment the rows land; the row statistics -- a reduction over the whole workgroup --
+    // are only needed by the epilogue and no longer stand between the loads and the first multiply (before: statistics, a workgroup
+    // barrier and a normalisation pass in front of every LN launch, ~0.8 us of its ~4 us fixed cost).
     if (LN) {
+        float4 gm[CH];
 #pragma unroll
-        for (int ch = 0; ch < CH; ++ch) {
-            gm[ch] = *((const float4*)(a.gamma + seg * SG_SEG + lane * 4) + ch * 64);
-            bt[ch] = *((const float4*)(a.beta + seg * SG_SEG + lane * 4) + ch * 64);
-        }
-        // per-lane partial sums of its 12 elements per row in fp32 (error <= 12 ulp of the partial), across lanes and segments in fp64
+        for (int ch = 0; ch < CH; ++ch) gm[ch] = *((const float4*)(a.gamma + seg * SG_SEG + lane * 4) + ch * 64);
+        // per-lane partial sums of its 12 raw elements per row in fp32 (error <= 12 ulp of the partial), across lanes and segments in fp64
         double st[2 * NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -173,34 +175,19 @@ __global__ __launch_bounds__(ROLE == SG_FC2 ? 512 : 256) void k_sgemv(SgArgs a) 
         int sidx;
         const double tot = wave_reduce_many<2 * NB, double>(st, lane, &sidx);
         constexpr int LB = sg_log2p<2 * NB>();
-        if ((lane & ((64 >> LB) - 1)) == 0 && sidx < 2 * NB) lnred[w * 2 * SG_MAX_ROWS + sidx] = tot;
-        __syncthreads();
-        const double invK = inv_count_f64((double)a.K);
+        if ((lane & ((64 >> LB) - 1)) == 0 && sidx < 2 * NB) lnred[w * 2 * SG_MAX_ROWS + sidx] = tot;      // read behind the final barrier
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            // segment 0 is wave 0, segment 1 is wave NSPLIT (LN roles have two segments)
-            const double sm = lnred[2 * b] + lnred[NSPLIT * 2 * SG_MAX_ROWS + 2 * b];
-            const double sq = lnred[2 * b + 1] + lnred[NSPLIT * 2 * SG_MAX_ROWS + 2 * b + 1];
-            const double mean = sm * invK;
-            mu[b] = (float)mean;
-            rstd[b] = rsqrtf((float)var_f64(sq * invK, mean) + 1e-5f);
-        }
+        for (int ch = 0; ch < CH; ++ch)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                xr[ch][b].x *= gm[ch].x; xr[ch][b].y *= gm[ch].y; xr[ch][b].z *= gm[ch].z; xr[ch][b].w *= gm[ch].w;
+            }
     }
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch)
 #pragma unroll
         for (int bp = 0; bp < NBP; ++bp) {
-            float4 v0 = xr[ch][2 * bp], v1 = 2 * bp + 1 < NB ? xr[ch][2 * bp + 1 < NB ? 2 * bp + 1 : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (LN) {
-                const float m0 = mu[2 * bp], r0 = rstd[2 * bp];
-                v0.x = (v0.x - m0) * r0 * gm[ch].x + bt[ch].x; v0.y = (v0.y - m0) * r0 * gm[ch].y + bt[ch].y;
-                v0.z = (v0.z - m0) * r0 * gm[ch].z + bt[ch].z; v0.w = (v0.w - m0) * r0 * gm[ch].w + bt[ch].w;
-                if (2 * bp + 1 < NB) {
-                    const float m1 = mu[2 * bp + 1 < NB ? 2 * bp + 1 : 0], r1 = rstd[2 * bp + 1 < NB ? 2 * bp + 1 : 0];
-                    v1.x = (v1.x - m1) * r1 * gm[ch].x + bt[ch].x; v1.y = (v1.y - m1) * r1 * gm[ch].y + bt[ch].y;
-                    v1.z = (v1.z - m1) * r1 * gm[ch].z + bt[ch].z; v1.w = (v1.w - m1) * r1 * gm[ch].w + bt[ch].w;
-                }
-            }
+            const float4 v0 = xr[ch][2 * bp], v1 = 2 * bp + 1 < NB ? xr[ch][2 * bp + 1 < NB ? 2 * bp + 1 : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
             x2[ch][0][bp] = f32x2{v0.x, v1.x}; x2[ch][1][bp] = f32x2{v0.y, v1.y};
             x2[ch][2][bp] = f32x2{v0.z, v1.z}; x2[ch][3][bp] = f32x2{v0.w, v1.w};
         }
@@ -243,7 +230,9 @@ __global__ __launch_bounds__(ROLE == SG_FC2 ? 512 : 256) void k_sgemv(SgArgs a) 
 #undef WMAR_SG_COMPUTE
     __syncthreads();
 
-    // segment sums in a fixed order + epilogue; column fastest so that the stores of a row are contiguous
+    // segment sums in a fixed order + epilogue; column fastest so that the stores of a row are contiguous.  LN roles: the row
+    // statistics the waves left in LDS (segment 0 = wave 0, segment 1 = wave NSPLIT) close the folded LayerNorm here.
+    const double invK = inv_count_f64((double)a.K);
     if (ROLE == SG_HEAD) {
         for (int t = threadIdx.x; t < cols_wg * NB; t += NW * 64) {
             const int b = t / cols_wg, col = t - b * cols_wg;
@@ -252,13 +241,20 @@ __global__ __launch_bounds__(ROLE == SG_FC2 ? 512 : 256) void k_sgemv(SgArgs a) 
             float s = part[(long long)col * NB + b];
 #pragma unroll
             for (int sg = 1; sg < NSEG; ++sg) s += part[((long long)sg * cols_wg + col) * NB + b];
-            a.out[(long long)b * a.N + n] = s;
+            const double mean = (lnred[2 * b] + lnred[NSPLIT * 2 * SG_MAX_ROWS + 2 * b]) * invK;
+            const float rstd = rsqrtf((float)var_f64((lnred[2 * b + 1] + lnred[NSPLIT * 2 * SG_MAX_ROWS + 2 * b + 1]) * invK, mean) + 1e-5f);
+            a.out[(long long)b * a.N + n] = rstd * (s - (float)mean * a.c1[n]) + (a.bias ? a.bias[n] : 0.f);
         }
     } else if (eon) {
         static_assert(ROLE == SG_HEAD || cols_wg * SG_MAX_ROWS <= NW * 64, "one epilogue value per thread");
         float s = part[(long long)ecol * NB + eb];
 #pragma unroll
         for (int sg = 1; sg < NSEG; ++sg) s += part[((long long)sg * cols_wg + ecol) * NB + eb];
+        if (LN) {
+            const double mean = (lnred[2 * eb] + lnred[NSPLIT * 2 * SG_MAX_ROWS + 2 * eb]) * invK;
+            const float rstd = rsqrtf((float)var_f64((lnred[2 * eb + 1] + lnred[NSPLIT * 2 * SG_MAX_ROWS + 2 * eb + 1]) * invK, mean) + 1e-5f);
+            s = rstd * (s - (float)mean * ec1);
+        }
         s += ebias;
         if (ROLE == SG_QKV) {
             const int pos = *a.pos_dev;

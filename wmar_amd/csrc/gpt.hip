@@ -338,7 +338,7 @@ struct StepPlan {
         const SmallW& w = g->sw[l];
         const long long lstride = (long long)g->Bmax * g->H * g->Tmax * g->hd;
         SgArgs a = sg_base();
-        a.W = w.wqkv; a.bias = w.bqkv; a.x = g->xs; a.gamma = w.ln1w; a.beta = w.ln1b; a.out = g->qs;
+        a.W = w.wqkv; a.bias = g->layers[l].bqkv; a.c1 = g->layers[l].cqkv; a.x = g->xs; a.gamma = w.ln1w; a.out = g->qs;      // (bias folded: b + W beta)
         a.kcache = g->kcache + l * lstride; a.vcache = g->vcache + l * lstride; a.N = 3 * D; a.K = D;
         g->span_begin(WMAR_T_QKV, st);
         const int rc = launch_sgemv<3, 3, SG_QKV>(a, (int)B, st);
@@ -450,7 +450,7 @@ struct StepPlan {
         if (small) {
             const SmallW& sw = g->sw[l];
             SgArgs a = sg_base();
-            a.W = sw.wfc1; a.bias = sw.bfc1; a.x = g->xs; a.gamma = sw.ln2w; a.beta = sw.ln2b; a.out = g->hs; a.N = 4 * D; a.K = D;
+            a.W = sw.wfc1; a.bias = g->layers[l].bfc1; a.c1 = g->layers[l].cfc1; a.x = g->xs; a.gamma = sw.ln2w; a.out = g->hs; a.N = 4 * D; a.K = D;
             g->span_begin(WMAR_T_FC1, st);
             const int rc = launch_sgemv<3, 4, SG_FC1>(a, (int)B, st);
             g->span_end(st);
@@ -498,7 +498,7 @@ struct StepPlan {
     int head() {
         if (small) {
             SgArgs a = sg_base();
-            a.W = g->whead_rm; a.x = g->xs; a.gamma = g->lnfw; a.beta = g->lnfb; a.out = io.logits; a.N = g->V; a.K = D;
+            a.W = g->whead_rm; a.bias = g->bhead; a.c1 = g->chead; a.x = g->xs; a.gamma = g->lnfw; a.out = io.logits; a.N = g->V; a.K = D;
             g->span_begin(WMAR_T_HEAD, st);
             const int rc = launch_sgemv<4, 8, SG_HEAD>(a, (int)B, st);
             g->span_end(st);
