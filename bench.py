@@ -278,6 +278,24 @@ def secondary_block(log, device="cuda"):
         log(f"secondary RAR-XL: {out}")
         del m, wm, gw
         gc.collect(); torch.cuda.empty_cache()
+        # the reference's own batch size (configs/rar_generate.json: 10 = 20 rows under guidance): the engine's one-row-tile plan
+        Br = 10
+        m = RarARMMWrapper.synthetic(max_batch=Br)
+        wm = GentimeWatermark(m.get_vq(), 1024, SeedStrategy.LINEAR, SplitStrategy.RANDOM_STRATIFIED, 1, 2.0, 0.25, device=device)
+        m.set_watermarker(wm)
+        cond_r = torch.arange(Br) % 1000
+        bb = None
+        for rep in range(2):
+            qn = m.draw_noise(Br)
+            sync(); t0 = time.perf_counter()
+            m.sample(cond_r, None, apply_watermark=True, q=qn)
+            sync(); bb = time.perf_counter() - t0
+        floor10 = (3.793e9 + 2 * 32 * 1280 * 4 * 129.5 * 2 * Br) / (PEAK_HBM_GBS * 1e9) * 1e3
+        out["rar_xl_b10"] = {"ms_per_step": round(bb / 257 * 1e3, 3), "sample_images_per_s": round(Br / bb, 2), "step_floor_ms": round(floor10, 3),
+                             "frac_of_step_floor": round(floor10 / (bb / 257 * 1e3), 3),
+                             "config": "RAR-XL at the reference's batch size (configs/rar_generate.json: 10 x 2 guidance rows), greenlist; sampling loop only"}
+        del m, wm
+        gc.collect(); torch.cuda.empty_cache()
     except Exception as e:      # a secondary config must never cost the headline line
         out["rar_xl_error"] = repr(e)
     try:
