@@ -73,3 +73,26 @@ def test_shapes_and_errors():
         D.run(D.BLUR, torch.rand(1, 3, 4, 4, device="cuda"), 19)                           # reflect padding needs k // 2 < size
     rect = torch.rand(2, 3, 24, 40, device="cuda")                                          # odd quarter turns of a non-square image: torch path
     assert Rotate()(rect, 90).shape == (2, 3, 40, 24)
+
+
+def test_harness_fuses_only_the_managers_own_callables():
+    """fill_batch_log replaces the AugmentationManager's entries by the fused launch (same pixels) and leaves a caller's own callable
+    registered under one of those names alone"""
+    from wmar_amd import harness
+
+    class M:
+        def codes_to_images(self, codes): return (codes.float().view(-1, 1, 8, 8).repeat(1, 3, 4, 4) / 32.0 - 1.0).cuda()
+        def images_to_codes(self, imgs): return ((imgs[:, 0, ::4, ::4] + 1.0) * 32.0).round().long().view(imgs.shape[0], -1)
+
+    codes = torch.randint(0, 64, (3, 64), device="cuda")
+    mine = lambda x, p: x * 0.0 + 0.25                                           # noqa: E731
+    table = [a for a in AugmentationManager(False, False, True).augs if a[0] == "brightness"]
+    logs = {}
+    for key, augs in (("default", table), ("custom", [("brightness", mine, [2.0])]), ("unfused", table)):
+        ev = {"metric_names": [], "augmentations": augs, "max_roundtrips": 0, "orig_only": False, "fuse_augmentations": key != "unfused"}
+        log = {}
+        harness.fill_batch_log(log, "m", M(), codes, ev)
+        logs[key] = log["m"]["brightness"]
+    assert np.allclose(logs["custom"][0][2], 0.25 * 2 - 1)                       # the caller's transform ran
+    for a, b in zip(logs["default"], logs["unfused"]):
+        assert a[0] == b[0] and np.array_equal(a[2], b[2]) and np.array_equal(a[1], b[1])

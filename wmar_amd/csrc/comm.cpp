@@ -43,7 +43,8 @@ Rccl& rccl() {
 
 int need_rccl() {
     if (rccl().ok) return WMAR_OK;
-    wmar::set_error("wmar_comm: librccl.so could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing");
+    const char* why = dlerror();
+    wmar::set_error("wmar_comm: librccl.so could not be loaded (%s)", why ? why : "symbols missing");
     return WMAR_EHIP;
 }
 

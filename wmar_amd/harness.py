@@ -66,7 +66,7 @@ def fill_batch_log(batch_log, key, model, codes, eval_params, sync_manager=None)
         for aug_param in aug_params:
             # one launch per (transform, parameter) over the whole batch where the transform has a device form (csrc/augment.hip:
             # range change, transform, clamp and range change back fused; bit-identical to the sequence below), else the module
-            aug_imgs = _dev_aug.fused(aug_name, imgs, aug_param) if fused_ok else None
+            aug_imgs = _dev_aug.fused(aug_name, imgs, aug_param) if (fused_ok and getattr(aug_fn, "_wmar_default", False)) else None
             if aug_imgs is None:
                 imgs_zero_to_one = imgs / 2.0 + 0.5
                 aug_imgs = aug_fn(imgs_zero_to_one, aug_param).clamp(0, 1) * 2.0 - 1.0
