@@ -69,6 +69,63 @@ def test_taming_generation_graph_replays_are_bit_reproducible(taming_engine):
         assert torch.equal(tok, tok0), f"graph replay {rep + 1}: tokens differ although the traced logits agree"
 
 
+@pytest.mark.parametrize("B", [1, 5])
+def test_taming_small_batch_plan_is_bit_reproducible(taming_engine, B):
+    """the weight-streaming plan of 1..8 rows (decode_small.h: wave butterflies, LDS segment sums in fixed order, no atomics): twelve
+    teacher-forced passes over 256 positions and five replays of the captured 256-step loop return the first pass's bits"""
+    cfg, eng = taming_engine
+    assert "k_sgemv" in eng.plan_info(B)["qkv"]
+    seq = torch.randint(0, cfg.vocab_size, (B, 256), generator=torch.Generator().manual_seed(50 + B)).cuda()
+    ref = torch.empty(256, B, cfg.vocab_size, device="cuda")
+    for t in range(256):
+        ref[t].copy_(eng.decode_step(seq[:, t], t))
+    for p in range(11):
+        for t in range(256):
+            lg = eng.decode_step(seq[:, t], t)
+            if not torch.equal(lg, ref[t]):
+                raise AssertionError(_diff_msg(f"batch {B}, pass {p + 1}, position {t}", lg, ref[t]))
+    torch.manual_seed(2)
+    q = torch.empty(256, B, cfg.vocab_size, device="cuda").exponential_(1)
+    cond = torch.tensor([1, 9, 232, 340, 568][:B], device="cuda")
+    tok0, tr0 = eng.generate(cond, 256, q, temperature=1.0, top_k=250, top_p=0.92, use_graph=True, trace_logits=True)
+    tok0, tr0 = tok0.clone(), tr0.clone()
+    for rep in range(4):
+        tok, tr = eng.generate(cond, 256, q, temperature=1.0, top_k=250, top_p=0.92, use_graph=True, trace_logits=True)
+        assert torch.equal(tr, tr0) and torch.equal(tok, tok0), f"batch {B}, graph replay {rep + 1}"
+
+
+def test_taming_persistent_step_is_bit_reproducible():
+    """the opt-in persistent step (decode_persist.h): its rows cross workgroups INSIDE a launch (agent-scope atomics behind a
+    device-wide barrier) -- a stale read would show as a run-to-run difference.  48 layers, batch 5: six teacher-forced passes over 128
+    positions and three replays of the captured loop, bit for bit; zero barrier fallbacks."""
+    import os
+    from wmar_amd.models.engine import GPTEngine
+    cfg = synth.TAMING_GPT
+    os.environ["WMAR_PERSIST"] = "1"
+    try:
+        eng = GPTEngine(cfg, synth.synth_gpt_state_fast(cfg, 0, "cuda", logit_scale=10.0), max_batch=5)
+    finally:
+        del os.environ["WMAR_PERSIST"]
+    if "persistent" not in eng.plan_info(5).get("path", ""):
+        pytest.skip("the persistent step is not available on this device")
+    seq = torch.randint(0, cfg.vocab_size, (5, 128), generator=torch.Generator().manual_seed(77)).cuda()
+    ref = torch.empty(128, 5, cfg.vocab_size, device="cuda")
+    for t in range(128):
+        ref[t].copy_(eng.decode_step(seq[:, t], t))
+    for p in range(5):
+        for t in range(128):
+            lg = eng.decode_step(seq[:, t], t)
+            if not torch.equal(lg, ref[t]):
+                raise AssertionError(_diff_msg(f"persistent step, pass {p + 1}, position {t}", lg, ref[t]))
+    torch.manual_seed(3)
+    q = torch.empty(256, 5, cfg.vocab_size, device="cuda").exponential_(1)
+    cond = torch.tensor([1, 9, 232, 340, 568], device="cuda")
+    tok0 = eng.generate(cond, 256, q, temperature=1.0, top_k=250, top_p=0.92, use_graph=True).clone()
+    for rep in range(3):
+        assert torch.equal(eng.generate(cond, 256, q, temperature=1.0, top_k=250, top_p=0.92, use_graph=True), tok0), rep
+    assert eng.plan_info(5)["barrier_fallbacks"] == "0"
+
+
 def test_rar_xl_step_is_bit_reproducible():
     from wmar_amd.models.engine import RAREngine
     cfg = synth.RAR_XL
