@@ -61,7 +61,7 @@ def cpu_model() -> str:
     return "unknown"
 
 
-def cpu_baseline(gpt_state_gpu, vq_state_gpu, gcfg, vcfg, wm, log, budget_s=75.0):
+def cpu_baseline(gpt_state_gpu, vq_state_gpu, gcfg, vcfg, wm, log, budget_s=75.0, model=None):
     """the CPU oracle (a port of the reference's path, parity-pinned in tests/) on this host's cores,
     fp32, on the two stated configurations -- Taming batch 1 (configs[0]) and batch 64 (configs[1]) -- with the stages timed
     separately: `sample` = 16 decode steps of the full 48-layer model incl. watermark + top-k/top-p + multinomial, extrapolated
@@ -87,10 +87,17 @@ def cpu_baseline(gpt_state_gpu, vq_state_gpu, gcfg, vcfg, wm, log, budget_s=75.0
             out.append(time.perf_counter() - t0)
         return out
 
+    checks = {}
+
     def sample_cfg(Bc):
         cond = torch.tensor([(i * 37) % 1000 for i in range(Bc)]).view(-1, 1)
         torch.manual_seed(1)
-        run = lambda n: M.sample_with_past(gs, gcfg.n_head, cond, n, 1.0, 250, 0.92, key, 2.0)
+        # the noise of the loop's multinomial draws, drawn up front (one [B, V] exponential per step, the reference's order) so that the
+        # SAME run can be replayed on the engine the headline was timed on: the oracle here is the checker of that 48-layer engine
+        qs = torch.empty(NSTEP, Bc, gcfg.vocab_size).exponential_(1)
+        last = {}
+        def run(n):
+            last["tok"] = M.sample_with_past(gs, gcfg.n_head, cond, n, 1.0, 250, 0.92, key, 2.0, q_source=lambda i, b, v: qs[i])
         t0 = time.perf_counter()
         run(1)                                                  # warm-up (thread pools, oracle .so)
         warm = time.perf_counter() - t0
@@ -98,6 +105,16 @@ def cpu_baseline(gpt_state_gpu, vq_state_gpu, gcfg, vcfg, wm, log, budget_s=75.0
         reps = 3 if warm * NSTEP * 3 < left else 1
         nstep = NSTEP if warm * NSTEP * reps < left * 1.5 else max(1, int(left / max(warm, 1e-3)))
         ts = [t / nstep for t in timed(lambda: run(nstep), reps)]
+        if model is not None:
+            try:
+                eng = model.model.transformer
+                got = eng.generate(cond.view(-1).to(model.model.device), nstep, qs[:nstep].contiguous().to(model.model.device), 1.0, 250, 0.92,
+                                   wm.wm_ctx(), use_graph=False).cpu()
+                ref = last["tok"]
+                checks[f"batch{Bc}"] = {"rows": Bc, "steps": nstep, "token_mismatches": int((got != ref).sum()),
+                                        "rows_equal": int((got == ref).all(1).sum()), "plan": eng.plan_info(Bc).get("path", "matrix-core plan")}
+            except Exception as e:
+                checks[f"batch{Bc}"] = {"error": repr(e)}
         return {"s_per_step": statistics.median(ts), "min": min(ts), "max": max(ts), "repeats": reps, "steps_timed": nstep}
 
     b1 = sample_cfg(1)
@@ -126,7 +143,9 @@ def cpu_baseline(gpt_state_gpu, vq_state_gpu, gcfg, vcfg, wm, log, budget_s=75.0
                         "sample_s_per_step_min_max": [r3(b64["min"]), r3(b64["max"])], "sample_s_per_image": r3(b64["s_per_step"] * S / B)},
             "batch1": {"images_per_s": 1.0 / per_img_1, "sample_s_per_step": r3(b1["s_per_step"]),
                        "sample_s_per_step_min_max": [r3(b1["min"]), r3(b1["max"])], "sample_s_per_image": r3(b1["s_per_step"] * S)},
-            "codes_to_images_s_per_image": r3(t_dec), "images_to_codes_s_per_image": r3(t_enc), "detect_s_per_image": round(t_det, 6)}
+            "codes_to_images_s_per_image": r3(t_dec), "images_to_codes_s_per_image": r3(t_enc), "detect_s_per_image": round(t_det, 6),
+            # the oracle as the checker of the TIMED engine (48 layers, this run's weights): the timed oracle steps replayed on it, same noise
+            "timed_engine_vs_oracle_tokens": checks or None}
 
 
 def parity_block(log):
@@ -552,7 +571,7 @@ def main():
             out["parity"] = None if args.no_parity else parity_block(log)
             out["cpu_baseline"] = None
             if world == 1 and not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(extra["gs"], extra["vs"], extra["gcfg"], extra["vcfg"], wm, log)
+                out["cpu_baseline"] = cpu_baseline(extra["gs"], extra["vs"], extra["gcfg"], extra["vcfg"], wm, log, model=model)
             out["secondary"] = None
             small = None
             if world == 1 and not args.no_secondary:
