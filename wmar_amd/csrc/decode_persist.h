@@ -34,6 +34,8 @@
 
 namespace wmar {
 
+#pragma clang fp contract(off)      // pinned arithmetic, as decode_small.h
+
 // The small-batch weights of all layers live in ONE allocation with a fixed per-layer stride, so that the kernel forms every address
 // from a kernel-argument base (global address space: `global_load`, counted by vmcnt only -- a pointer fetched from a table in memory is
 // a flat pointer, and flat loads also count on lgkmcnt, which the workgroup barrier below waits for).  Offsets in floats, n_embd 1536.
@@ -159,8 +161,8 @@ template <int ROLE> __host__ __device__ constexpr int ss_K() { return ROLE == SS
                 _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                                    \
                     const float4 wv = BUF[c * 3 + ch];                                                             \
                     f32x2 s_ = acc2[c][bp];                                                                        \
-                    s_ = f32x2{wv.x, wv.x} * xx + s_; s_ = f32x2{wv.y, wv.y} * xy + s_;                           \
-                    s_ = f32x2{wv.z, wv.z} * xz + s_; s_ = f32x2{wv.w, wv.w} * xw + s_;                           \
+                    s_ = __builtin_elementwise_fma(f32x2{wv.x, wv.x}, xx, s_); s_ = __builtin_elementwise_fma(f32x2{wv.y, wv.y}, xy, s_); \
+                    s_ = __builtin_elementwise_fma(f32x2{wv.z, wv.z}, xz, s_); s_ = __builtin_elementwise_fma(f32x2{wv.w, wv.w}, xw, s_); \
                     acc2[c][bp] = s_;                                                                              \
                 }                                                                                                  \
             }                                                                                                      \
@@ -397,8 +399,8 @@ __global__ __launch_bounds__(SS_THREADS) void k_sstep(SsArgs a) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float e = expf(sm[i] - M);
-                    Ls += sl[i] * e;
-                    O += so[i * 64 + lane] * e;
+                    Ls = fmaf(sl[i], e, Ls);
+                    O = fmaf(so[i * 64 + lane], e, O);
                 }
                 st_x1(a.ys + (long long)b * a.D + h * 64 + lane, O / Ls);
             }
@@ -497,8 +499,8 @@ __global__ __launch_bounds__(SS_THREADS) void k_sstep(SsArgs a) {
                     for (int c = 0; c < 4; ++c) {
                         const float4 wv = hb[g & 1][c * 3 + ch];
                         f32x2 s = acc2[c][bp];
-                        s = f32x2{wv.x, wv.x} * xx + s; s = f32x2{wv.y, wv.y} * xy + s;
-                        s = f32x2{wv.z, wv.z} * xz + s; s = f32x2{wv.w, wv.w} * xw + s;
+                        s = __builtin_elementwise_fma(f32x2{wv.x, wv.x}, xx, s); s = __builtin_elementwise_fma(f32x2{wv.y, wv.y}, xy, s);
+                        s = __builtin_elementwise_fma(f32x2{wv.z, wv.z}, xz, s); s = __builtin_elementwise_fma(f32x2{wv.w, wv.w}, xw, s);
                         acc2[c][bp] = s;
                     }
                 }
@@ -558,5 +560,7 @@ static int sstep_blocks_per_cu() {
     for (int i = 1; i < 5; ++i) m = v[i] < m ? v[i] : m;
     return m;
 }
+
+#pragma clang fp contract(fast)
 
 }  // namespace wmar

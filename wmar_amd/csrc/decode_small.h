@@ -29,6 +29,12 @@
 
 namespace wmar {
 
+// The arithmetic of this file is PINNED: no implicit fp contraction (the compiler's choice between a fused and an unfused a * b + c
+// follows its scheduling context -- round 6: two builds that differed only in how a wave reduction moved data returned LayerNorm
+// statistics one ulp apart for one row in ~40, because the sum of squares was fused in one and not in the other); every fused
+// multiply-add below is written as one (fmaf / __builtin_elementwise_fma).  Restored at the end of decode_persist.h / this file.
+#pragma clang fp contract(off)
+
 enum { SG_QKV = 0, SG_PROJ = 1, SG_FC1 = 2, SG_FC2 = 3, SG_HEAD = 4 };
 constexpr int SG_CH = 3;                 // 1-KiB loads per (column, segment): segment = 768 k
 constexpr int SG_SEG = SG_CH * 256;
@@ -52,6 +58,34 @@ struct SgArgs {
 // lane keeps one of a pair and sends the other), so the whole reduction is P - 1 + (6 - log2 P) shuffles for P = R rounded up to a
 // power of two, instead of 6 R.  On return v[0] of lane l is the total of value `idx`, idx = sum_j bit(l, 5 - j) << j over the
 // log2 P halving steps (lanes that differ only in the low bits hold copies).  Fixed order: the result is a function of the inputs only.
+// The two widest steps of the butterfly on gfx950's lane-swap instructions: v_permlane32_swap exchanges lanes 32..63 of its first
+// operand with lanes 0..31 of its second (v_permlane16_swap: the odd 16-lane rows of the first with the even rows of the second), so
+// swap(a, b) followed by ONE add leaves a's pair sums in the lower lanes and b's in the upper ones -- the keep / send selects and the
+// LDS-crossbar shuffle of the generic step (2 v_cndmask + ds_bpermute + add per pair) become one VALU swap + add.  Same operands,
+// same order: bit-identical results.
+template <int OFF>
+__device__ __forceinline__ float tb_pair(float a, float b) {
+    static_assert(OFF == 32 || OFF == 16, "lane-swap steps");
+    if (OFF == 32) { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false); return __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int OFF>
+__device__ __forceinline__ double tb_pair(double a, double b) {
+    const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+    unsigned lo0, lo1, hi0, hi1;
+    if (OFF == 32) {
+        const auto l = __builtin_amdgcn_permlane32_swap((unsigned)ua, (unsigned)ub, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+        lo0 = l[0]; lo1 = l[1]; hi0 = h[0]; hi1 = h[1];
+    } else {
+        const auto l = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+        lo0 = l[0]; lo1 = l[1]; hi0 = h[0]; hi1 = h[1];
+    }
+    return __longlong_as_double((long long)(((unsigned long long)hi0 << 32) | lo0)) + __longlong_as_double((long long)(((unsigned long long)hi1 << 32) | lo1));
+}
+
 template <int R, typename T>
 __device__ __forceinline__ T wave_reduce_many(T (&v)[R], int lane, int* idx_out) {
     constexpr int P = R <= 1 ? 1 : R <= 2 ? 2 : R <= 4 ? 4 : R <= 8 ? 8 : R <= 16 ? 16 : R <= 32 ? 32 : 64;
@@ -68,6 +102,10 @@ __device__ __forceinline__ T wave_reduce_many(T (&v)[R], int lane, int* idx_out)
 #pragma unroll
             for (int i = 0; i < P / 2; ++i) {
                 if (i < cnt / 2) {
+#ifndef WMAR_SG_NO_SWAP
+                    if (step == 0) { t[i] = tb_pair<32>(t[2 * i], t[2 * i + 1]); continue; }
+                    if (step == 1) { t[i] = tb_pair<16>(t[2 * i], t[2 * i + 1]); continue; }
+#endif
                     const T keep = up ? t[2 * i + 1] : t[2 * i];
                     const T send = up ? t[2 * i] : t[2 * i + 1];
                     t[i] = keep + __shfl_xor(send, off);
@@ -76,6 +114,11 @@ __device__ __forceinline__ T wave_reduce_many(T (&v)[R], int lane, int* idx_out)
             idx |= (up ? 1 : 0) << j;
             cnt /= 2; ++j;
         } else {
+#ifndef WMAR_SG_NO_SWAP
+            if (step == 0) t[0] = tb_pair<32>(t[0], t[0]);
+            else if (step == 1) t[0] = tb_pair<16>(t[0], t[0]);
+            else
+#endif
             t[0] += __shfl_xor(t[0], off);
         }
         off >>= 1;
@@ -146,6 +189,10 @@ __global__ __launch_bounds__(ROLE == SG_FC2 ? 512 : 256) void k_sgemv(SgArgs a) 
     WMAR_SG_LOADW(wbuf[0], 0)
     if (G > 1) WMAR_SG_LOADW(wbuf[1], 1)
     if (G > 2) WMAR_SG_LOADW(wbuf[2], 2)
+    // roles without LayerNorm: every request above goes out before any arithmetic below (the scheduler otherwise sinks the weight loads
+    // behind the first multiplies to save registers: FC2 9.1 -> 10.9 us per launch at 5 rows); the LayerNorm roles are faster WITHOUT the
+    // fence (QKV 8.0 against 8.8, FC1 8.8 against 9.6: their statistics arithmetic interleaves with the issue of the requests)
+    if (!LN) __builtin_amdgcn_sched_barrier(0);
     // Rows in PAIRS: x2[ch][component][pair] = (row 2p, row 2p + 1) -- one v_pk_fma_f32 per weight component and row pair, the weight
     // splat over both halves (the multiply-adds are what the vector ALU spends its time on: 4 x rows per 16 weight bytes).
     constexpr int NBP = (NB + 1) / 2;
@@ -203,8 +250,8 @@ __global__ __launch_bounds__(ROLE == SG_FC2 ? 512 : 256) void k_sgemv(SgArgs a) 
                 const f32x2 wx = {wv.x, wv.x}, wy = {wv.y, wv.y}, wz = {wv.z, wv.z}, ww = {wv.w, wv.w}; \
                 _Pragma("unroll") for (int bp = 0; bp < NBP; ++bp) {                           \
                     f32x2 s_ = acc2[c][bp];                                                    \
-                    s_ = wx * x2[ch][0][bp] + s_; s_ = wy * x2[ch][1][bp] + s_;               \
-                    s_ = wz * x2[ch][2][bp] + s_; s_ = ww * x2[ch][3][bp] + s_;               \
+                    s_ = __builtin_elementwise_fma(wx, x2[ch][0][bp], s_); s_ = __builtin_elementwise_fma(wy, x2[ch][1][bp], s_); \
+                    s_ = __builtin_elementwise_fma(wz, x2[ch][2][bp], s_); s_ = __builtin_elementwise_fma(ww, x2[ch][3][bp], s_); \
                     acc2[c][bp] = s_;                                                          \
                 }                                                                              \
             }                                                                                  \
@@ -330,11 +377,13 @@ __device__ __forceinline__ void sattn_rows(const float4* __restrict__ Kp, const 
         kb[i] = ld_nt(Kp + (long long)row * 16);
         vb[i] = ld_nt(Vp + (long long)row * 16);
     }
+    __builtin_amdgcn_sched_barrier(0);       // all 2 NU requests in flight before the first score (without it the scheduler interleaves
+                                             // loads and arithmetic to save registers: 100 instead of 186 VGPRs, 6.0 -> 8.3 us per launch)
     float sc[NU];
     float mt = -INFINITY;
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
-        float s = q4.x * kb[i].x + q4.y * kb[i].y + q4.z * kb[i].z + q4.w * kb[i].w;
+        float s = fmaf(q4.w, kb[i].w, fmaf(q4.z, kb[i].z, fmaf(q4.y, kb[i].y, q4.x * kb[i].x)));
         s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
         s = (4 * (u0 + 4 * i) + rr < T) ? s * scale : -INFINITY;
         sc[i] = s;
@@ -349,10 +398,10 @@ __device__ __forceinline__ void sattn_rows(const float4* __restrict__ Kp, const 
     for (int i = 0; i < NU; ++i) {
         const float pe = expf(sc[i] - ms);
         lt += pe;
-        ot.x += pe * vb[i].x; ot.y += pe * vb[i].y; ot.z += pe * vb[i].z; ot.w += pe * vb[i].w;
+        ot.x = fmaf(pe, vb[i].x, ot.x); ot.y = fmaf(pe, vb[i].y, ot.y); ot.z = fmaf(pe, vb[i].z, ot.z); ot.w = fmaf(pe, vb[i].w, ot.w);
     }
-    l = l * corr + lt;
-    o.x = o.x * corr + ot.x; o.y = o.y * corr + ot.y; o.z = o.z * corr + ot.z; o.w = o.w * corr + ot.w;
+    l = fmaf(l, corr, lt);
+    o.x = fmaf(o.x, corr, ot.x); o.y = fmaf(o.y, corr, ot.y); o.z = fmaf(o.z, corr, ot.z); o.w = fmaf(o.w, corr, ot.w);
     m = mn;
 }
 
@@ -386,8 +435,8 @@ __global__ __launch_bounds__(256) void k_sattn(SaArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float e = expf(sm[i] - M);            // groups without a row: exp(-inf) = 0
-            L += sl[i] * e;
-            O += so[i][threadIdx.x] * e;
+            L = fmaf(sl[i], e, L);
+            O = fmaf(so[i][threadIdx.x], e, O);
         }
         a.y[(long long)b * a.D + h * 64 + threadIdx.x] = O / L;
     }
@@ -409,5 +458,7 @@ __global__ __launch_bounds__(256) void k_sembed(SeArgs a) {
     const float4 pe = *((const float4*)(a.pos_emb + (long long)pos * a.D) + k4);
     *((float4*)(a.x + (long long)b * a.D) + k4) = make_float4(e.x + pe.x, e.y + pe.y, e.z + pe.z, e.w + pe.w);
 }
+
+#pragma clang fp contract(fast)
 
 }  // namespace wmar

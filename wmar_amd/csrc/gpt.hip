@@ -1060,6 +1060,17 @@ int wmar_gpt_debug_sums(wmar_gpt* g, unsigned long long* out, int n_out, int* n_
 #endif
 
 #ifdef WMAR_DEV_KNOBS
+// dev only: the small-batch plan's exchange buffers after the last step: which = 0 xs, 1 qs, 2 ys, 3 hs (4 D wide) -> out[8][width]
+int wmar_gpt_debug_small(wmar_gpt* g, int which, float* out) {
+    WMAR_REQUIRE(g && g->small_ok && out && which >= 0 && which <= 3, "debug_small: bad argument");
+    WMAR_HIP_CHECK(hipDeviceSynchronize());
+    const float* src = which == 0 ? g->xs : which == 1 ? g->qs : which == 2 ? g->ys : g->hs;
+    WMAR_HIP_CHECK(hipMemcpy(out, src, (size_t)SG_MAX_ROWS * (which == 3 ? 4 : 1) * g->D * 4, hipMemcpyDeviceToHost));
+    return WMAR_OK;
+}
+#endif
+
+#ifdef WMAR_DEV_KNOBS
 // dev only: row `pos` of every layer's K (which = 0) or V (1) cache -> out[L][Bmax][H][hd] on the host: the per-layer fingerprint of a
 // step that costs the step itself nothing (scripts/stress_kv.py)
 int wmar_gpt_debug_kv_row(wmar_gpt* g, int which, int pos, float* out) {
