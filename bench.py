@@ -213,8 +213,8 @@ def small_batch_block(model, wm, gcfg, log):
     out = {}
     eng = model.model.transformer
     L, D, V = gcfg.n_layer, gcfg.n_embd, gcfg.vocab_size
-    classes = [1, 9, 232, 340, 568]                      # configs/taming_generate.json
-    for name, Bs in (("taming_b1", 1), ("taming_b5", 5)):
+    classes = [1, 9, 232, 340, 568, 656, 703, 814, 937, 975]      # configs/taming_generate.json
+    for name, Bs in (("taming_b1", 1), ("taming_b5", 5), ("taming_b10", 10)):      # configs[0]; the published run; generate.py's default
         cond = torch.tensor(classes[:Bs], device=model.model.device)
         best = None
         for rep in range(3):

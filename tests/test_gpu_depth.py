@@ -56,9 +56,9 @@ def test_taming_48_layers_teacher_forced_logits(gpt48):
     eng, sd = gpt48
     cfg = synth.TAMING_GPT
     rs = np.random.RandomState(48)
-    # 64 rows: the benchmark's matrix-core plan; 8 / 5 / 1 rows: the weight-streaming plan of decode_small.h (the reference's own
+    # 64 rows: the benchmark's matrix-core plan; 10 / 8 / 5 / 1 rows: the weight-streaming plan of decode_small.h (the reference's own
     # batch sizes are 1 and 5: BASELINE configs[0], configs/taming_generate.json)
-    for rows, T, positions in ((64, 40, [0, 1, 39]), (8, 256, [113, 255]), (5, 160, [0, 1, 159]), (1, 72, [0, 71])):
+    for rows, T, positions in ((64, 40, [0, 1, 39]), (8, 256, [113, 255]), (5, 160, [0, 1, 159]), (1, 72, [0, 71]), (10, 48, [0, 47])):
         seq = torch.from_numpy(rs.randint(0, cfg.vocab_size, size=(rows, T)).astype(np.int64))
         t0 = time.perf_counter()
         ref = M.gpt_prefix(sd, cfg.n_head, seq, positions).numpy()            # [rows, len(positions), V]

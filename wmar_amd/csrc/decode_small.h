@@ -1,10 +1,10 @@
-// Small-batch decode step (1..8 sequences) of the Taming minGPT engine: weight STREAMING kernels, no matrix cores.
+// Small-batch decode step (1..10 sequences) of the Taming minGPT engine: weight STREAMING kernels, no matrix cores.
 //
 // Reference: deps/taming/modules/transformer/mingpt.py:69-95 (attention), :112-122 (Block), :183-214 (forward_with_past) at the batch
 // sizes the reference itself runs (configs/taming_generate.json: batch 5; BASELINE configs[0]: batch 1).
 //
-// Why a second path.  At <= 8 rows a decode step is the 5.54 GB weight stream and nothing else (0.69 ms at 8 TB/s): every weight
-// feeds <= 8 multiply-adds, so a 32-row MFMA tile is 75-97 % padding and the fp32 matrix pipe itself becomes the bound (32x32x2:
+// Why a second path.  At <= 12 rows a decode step is the 5.54 GB weight stream and nothing else (0.69 ms at 8 TB/s): every weight
+// feeds <= 12 multiply-adds, so a 32-row MFMA tile is 62-97 % padding and the fp32 matrix pipe itself becomes the bound (32x32x2:
 // 0.56 ms per step at peak), and the big-batch plan's split-K slabs + fold launches are pure fixed cost (round 5: 2.7 ms per step at
 // batch 5 = 0.25 of the stream).  Here a step is FIVE launches per layer and no partial sums ever leave a workgroup:
 //
@@ -17,13 +17,13 @@
 // k_sgemv: the weights stay in the checkpoint's own row-major [N][K] layout; a wave-wide 16-byte load is 1 KiB = 256 consecutive k of
 // ONE output column, so a workgroup can own ANY number of columns and every launch is exactly 256 workgroups (18 / 6 / 24 / 6 / 64
 // columns for QKV / proj / FC1 / FC2 / head at n_embd 1536) with whole K inside the workgroup.  K is cut into segments of 768 (three
-// loads per lane); a wave owns one segment and a column range, keeps its slice of the <= 8 activation rows in REGISTERS (12 VGPRs per
+// loads per lane); a wave owns one segment and a column range, keeps its slice of the <= 12 activation rows in REGISTERS (12 VGPRs per
 // row, LayerNorm applied once while they are loaded: every workgroup recomputes the row statistics from the 6 KB rows it reads
-// anyway), and turns every weight load into 4 x rows fused multiply-adds on the vector ALU (rows <= 8: <= 45 % of the VALU rate at
+// anyway), and turns every weight load into 4 x rows fused multiply-adds on the vector ALU (8 rows: 45 % of the VALU rate at
 // the HBM rate a CU can get).  Lane-partial dot products of a group of CG columns x rows meet in ONE transposing butterfly
 // (values halve while lane distance halves: ~CG x rows shuffles instead of 6 per value), the segments' partial sums meet in LDS in a
-// fixed order -- deterministic, no atomics.  Weight loads are non-temporal and double-buffered by column group; the first group is
-// requested before anything else in the kernel (the weights do not depend on the launch in front).
+// fixed order -- deterministic, no atomics.  Weight loads are non-temporal and double-buffered by column group.  The two widest steps
+// of every butterfly run on gfx950's v_permlane32_swap / v_permlane16_swap (tb_pair below).
 #pragma once
 #include "decoder_kernels.h"
 
@@ -38,7 +38,7 @@ namespace wmar {
 enum { SG_QKV = 0, SG_PROJ = 1, SG_FC1 = 2, SG_FC2 = 3, SG_HEAD = 4 };
 constexpr int SG_CH = 3;                 // 1-KiB loads per (column, segment): segment = 768 k
 constexpr int SG_SEG = SG_CH * 256;
-constexpr int SG_MAX_ROWS = 8;
+constexpr int SG_MAX_ROWS = 12;              // up to 12 rows (generate.py's default batch size is 10) since the lane-swap butterflies: ~+1 us per row and layer
 
 struct SgArgs {
     const float* W;        // [N][K] row-major (the checkpoint's layout)
@@ -151,7 +151,9 @@ __global__ __launch_bounds__(ROLE == SG_FC2 ? 512 : 256) void k_sgemv(SgArgs a) 
     const long long K = a.K;
     const float* wbase = a.W + (long long)seg * SG_SEG + lane * 4;
 
-    constexpr int NBUF = G >= 3 ? 3 : 2;                  // weight groups in flight per wave (9 or 12 KiB each)
+    // weight groups in flight per wave (9 or 12 KiB each).  TWO at every row count: a third one (round 6, first version) cost registers
+    // the row pairs need -- 6 / 7 rows 2.03 / 2.17 -> 1.83 / 1.90 ms per step without it, 1..5 rows equal or 1-2 % better
+    constexpr int NBUF = 2;
     float4 wbuf[NBUF][CG * CH];
 #define WMAR_SG_LOADW(BUF, GI)                                                                 \
     {                                                                                          \
@@ -165,15 +167,20 @@ __global__ __launch_bounds__(ROLE == SG_FC2 ? 512 : 256) void k_sgemv(SgArgs a) 
 
     // the epilogue's operands (bias, the residual value a column owner adds to) are requested here, not behind the reduction: a
     // dependent global round trip at the end of every launch otherwise (~1 us of each launch's ~4 us fixed cost)
-    const int et = threadIdx.x;
-    const int eb = et / cols_wg, ecol = et - eb * cols_wg;
-    const int en = blockIdx.x * cols_wg + ecol;
-    const bool eon = ROLE != SG_HEAD && et < cols_wg * NB && en < a.N;
-    float ebias = 0.f, eold = 0.f, ec1 = 0.f;
-    if (eon) {
-        ebias = a.bias[en];
-        if (LN) ec1 = a.c1[en];
-        if (ROLE == SG_PROJ || ROLE == SG_FC2) eold = a.out[(long long)eb * a.N + en];
+    constexpr int EPT = ROLE == SG_HEAD ? 1 : (cols_wg * NB + NW * 64 - 1) / (NW * 64);      // epilogue values per thread (2 for FC1 at 11 / 12 rows)
+    float ebias[EPT], eold[EPT], ec1[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int et = threadIdx.x + e * NW * 64;
+        const int eb = et / cols_wg, ecol = et - eb * cols_wg;
+        const int en = blockIdx.x * cols_wg + ecol;
+        const bool eon = ROLE != SG_HEAD && et < cols_wg * NB && en < a.N;
+        ebias[e] = 0.f; eold[e] = 0.f; ec1[e] = 0.f;
+        if (eon) {
+            ebias[e] = a.bias[en];
+            if (LN) ec1[e] = a.c1[en];
+            if (ROLE == SG_PROJ || ROLE == SG_FC2) eold[e] = a.out[(long long)eb * a.N + en];
+        }
     }
 
     // this wave's slice of the input rows (and of the LayerNorm parameters)
@@ -219,10 +226,22 @@ __global__ __launch_bounds__(ROLE == SG_FC2 ? 512 : 256) void k_sgemv(SgArgs a) 
             }
             st[2 * b] = (double)s; st[2 * b + 1] = (double)ss;
         }
-        int sidx;
-        const double tot = wave_reduce_many<2 * NB, double>(st, lane, &sidx);
-        constexpr int LB = sg_log2p<2 * NB>();
-        if ((lane & ((64 >> LB) - 1)) == 0 && sidx < 2 * NB) lnred[w * 2 * SG_MAX_ROWS + sidx] = tot;      // read behind the final barrier
+        if (2 * NB <= 16) {
+            int sidx;
+            const double tot = wave_reduce_many<2 * NB, double>(st, lane, &sidx);
+            constexpr int LB = sg_log2p<2 * NB>();
+            if ((lane & ((64 >> LB) - 1)) == 0 && sidx < 2 * NB) lnred[w * 2 * SG_MAX_ROWS + sidx] = tot;      // read behind the final barrier
+        } else {            // 9 / 10 rows: sums and sums of squares in two butterflies of <= 16 values (registers)
+            double sa[NB], sb[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { sa[b] = st[2 * b]; sb[b] = st[2 * b + 1]; }
+            constexpr int LB = sg_log2p<NB>();
+            int ia, ib;
+            const double ta = wave_reduce_many<NB, double>(sa, lane, &ia);
+            if ((lane & ((64 >> LB) - 1)) == 0 && ia < NB) lnred[w * 2 * SG_MAX_ROWS + 2 * ia] = ta;
+            const double tb = wave_reduce_many<NB, double>(sb, lane, &ib);
+            if ((lane & ((64 >> LB) - 1)) == 0 && ib < NB) lnred[w * 2 * SG_MAX_ROWS + 2 * ib + 1] = tb;
+        }
 #pragma unroll
         for (int ch = 0; ch < CH; ++ch)
 #pragma unroll
@@ -258,12 +277,24 @@ __global__ __launch_bounds__(ROLE == SG_FC2 ? 512 : 256) void k_sgemv(SgArgs a) 
         float acc[R];                                                                          \
         _Pragma("unroll") for (int c = 0; c < CG; ++c)                                         \
             _Pragma("unroll") for (int b = 0; b < NB; ++b) acc[c * NB + b] = (b & 1) ? acc2[c][b >> 1].y : acc2[c][b >> 1].x; \
-        int ridx;                                                                              \
-        const float tot_ = wave_reduce_many<R, float>(acc, lane, &ridx);                       \
-        constexpr int LBR = sg_log2p<R>();                                                     \
-        if ((lane & ((64 >> LBR) - 1)) == 0 && ridx < R) {                                     \
-            const int c_ = ridx / NB, b_ = ridx - c_ * NB;                                     \
-            part[((long long)seg * cols_wg + chalf * cols_wave + (GI) * CG + c_) * NB + b_] = tot_; \
+        if (R <= 32) {                                                                         \
+            int ridx;                                                                          \
+            const float tot_ = wave_reduce_many<R, float>(acc, lane, &ridx);                   \
+            constexpr int LBR = sg_log2p<R>();                                                 \
+            if ((lane & ((64 >> LBR) - 1)) == 0 && ridx < R) {                                 \
+                const int c_ = ridx / NB, b_ = ridx - c_ * NB;                                 \
+                part[((long long)seg * cols_wg + chalf * cols_wave + (GI) * CG + c_) * NB + b_] = tot_; \
+            }                                                                                  \
+        } else {       /* more than 32 values (the head at 9 / 10 rows): one butterfly per column */ \
+            _Pragma("unroll") for (int c = 0; c < CG; ++c) {                                   \
+                float col_[NB];                                                                \
+                _Pragma("unroll") for (int b = 0; b < NB; ++b) col_[b] = acc[c * NB + b];      \
+                int ridx;                                                                      \
+                const float tot_ = wave_reduce_many<NB, float>(col_, lane, &ridx);             \
+                constexpr int LBR = sg_log2p<NB>();                                            \
+                if ((lane & ((64 >> LBR) - 1)) == 0 && ridx < NB)                              \
+                    part[((long long)seg * cols_wg + chalf * cols_wave + (GI) * CG + c) * NB + ridx] = tot_; \
+            }                                                                                  \
         }                                                                                      \
     }
 
@@ -292,30 +323,36 @@ __global__ __launch_bounds__(ROLE == SG_FC2 ? 512 : 256) void k_sgemv(SgArgs a) 
             const float rstd = rsqrtf((float)var_f64((lnred[2 * b + 1] + lnred[NSPLIT * 2 * SG_MAX_ROWS + 2 * b + 1]) * invK, mean) + 1e-5f);
             a.out[(long long)b * a.N + n] = rstd * (s - (float)mean * a.c1[n]) + (a.bias ? a.bias[n] : 0.f);
         }
-    } else if (eon) {
-        static_assert(ROLE == SG_HEAD || cols_wg * SG_MAX_ROWS <= NW * 64, "one epilogue value per thread");
-        float s = part[(long long)ecol * NB + eb];
+    } else {
 #pragma unroll
-        for (int sg = 1; sg < NSEG; ++sg) s += part[((long long)sg * cols_wg + ecol) * NB + eb];
-        if (LN) {
-            const double mean = (lnred[2 * eb] + lnred[NSPLIT * 2 * SG_MAX_ROWS + 2 * eb]) * invK;
-            const float rstd = rsqrtf((float)var_f64((lnred[2 * eb + 1] + lnred[NSPLIT * 2 * SG_MAX_ROWS + 2 * eb + 1]) * invK, mean) + 1e-5f);
-            s = rstd * (s - (float)mean * ec1);
-        }
-        s += ebias;
-        if (ROLE == SG_QKV) {
-            const int pos = *a.pos_dev;
-            const int which = en / a.D, j = en - which * a.D;
-            if (which == 0) a.out[(long long)eb * a.D + j] = s;
-            else {
-                const int h = j >> 6, d = j & 63;
-                float* cache = which == 1 ? a.kcache : a.vcache;
-                cache[(((long long)eb * a.H + h) * a.Tmax + pos) * 64 + d] = s;
+        for (int e = 0; e < EPT; ++e) {
+            const int et = threadIdx.x + e * NW * 64;
+            const int eb = et / cols_wg, ecol = et - eb * cols_wg;
+            const int en = blockIdx.x * cols_wg + ecol;
+            if (!(et < cols_wg * NB && en < a.N)) continue;
+            float s = part[(long long)ecol * NB + eb];
+#pragma unroll
+            for (int sg = 1; sg < NSEG; ++sg) s += part[((long long)sg * cols_wg + ecol) * NB + eb];
+            if (LN) {
+                const double mean = (lnred[2 * eb] + lnred[NSPLIT * 2 * SG_MAX_ROWS + 2 * eb]) * invK;
+                const float rstd = rsqrtf((float)var_f64((lnred[2 * eb + 1] + lnred[NSPLIT * 2 * SG_MAX_ROWS + 2 * eb + 1]) * invK, mean) + 1e-5f);
+                s = rstd * (s - (float)mean * ec1[e]);
             }
-        } else if (ROLE == SG_PROJ || ROLE == SG_FC2) {
-            a.out[(long long)eb * a.N + en] = eold + s;
-        } else {
-            a.out[(long long)eb * a.N + en] = gelu_erf(s);
+            s += ebias[e];
+            if (ROLE == SG_QKV) {
+                const int pos = *a.pos_dev;
+                const int which = en / a.D, j = en - which * a.D;
+                if (which == 0) a.out[(long long)eb * a.D + j] = s;
+                else {
+                    const int h = j >> 6, d = j & 63;
+                    float* cache = which == 1 ? a.kcache : a.vcache;
+                    cache[(((long long)eb * a.H + h) * a.Tmax + pos) * 64 + d] = s;
+                }
+            } else if (ROLE == SG_PROJ || ROLE == SG_FC2) {
+                a.out[(long long)eb * a.N + en] = eold[e] + s;
+            } else {
+                a.out[(long long)eb * a.N + en] = gelu_erf(s);
+            }
         }
     }
 }
@@ -348,7 +385,11 @@ static int launch_sgemv(const SgArgs& a, int rows, hipStream_t st) {
         case 6: return launch_sgemv_nb<6, CG, G, ROLE>(a, st);
         case 7: return launch_sgemv_nb<7, CG, G, ROLE>(a, st);
         case 8: return launch_sgemv_nb<8, CG, G, ROLE>(a, st);
-        default: set_error("k_sgemv: %d rows (1..8)", rows); return WMAR_EINVAL;
+        case 9: return launch_sgemv_nb<9, CG, G, ROLE>(a, st);
+        case 10: return launch_sgemv_nb<10, CG, G, ROLE>(a, st);
+        case 11: return launch_sgemv_nb<11, CG, G, ROLE>(a, st);
+        case 12: return launch_sgemv_nb<12, CG, G, ROLE>(a, st);
+        default: set_error("k_sgemv: %d rows (1..%d)", rows, SG_MAX_ROWS); return WMAR_EINVAL;
     }
 }
 

@@ -50,7 +50,7 @@ struct wmar_gpt {
     std::vector<void*> allocs;
     int64_t bytes = 0;
     std::vector<LayerW> layers;
-    // small-batch path (1..8 rows, n_embd 1536, head_dim 64): streaming kernels on row-major weights, five launches per layer
+    // small-batch path (1..12 rows, n_embd 1536, head_dim 64): streaming kernels on row-major weights, five launches per layer
     std::vector<SmallW> sw;
     float *whead_rm = nullptr, *lnfw = nullptr, *lnfb = nullptr;
     float *xs = nullptr, *ys = nullptr, *hs = nullptr, *qs = nullptr;     // [8][D], [8][D], [8][4D], [8][D] row-major
@@ -220,7 +220,7 @@ struct StepPlan {
     bool proj_bx = false;     // 33..64 rows, n_embd a multiple of 384: output projection as k_bx on the attention's bf16 pieces
     bool proj_xr = false;     // ... with the residual fold + LN2 statistics inside the launch (k_bx_xr): no k_resid_stats behind it
     int nch_ln2 = 0;          // statistics chunks the FC1 launch reads (16 = two per XCD group behind k_bx_xr)
-    bool small = false;       // 1..8 rows on an eligible engine: the streaming path of decode_small.h
+    bool small = false;       // 1..12 rows on an eligible engine: the streaming path of decode_small.h
     bool persist = false;     // 1..5 rows: the whole step as one persistent launch (decode_persist.h)
 
     StepPlan(wmar_gpt* g_, int64_t B_, const StepIO& io_, hipStream_t st_) : g(g_), B(B_), io(io_), st(st_) {
@@ -558,7 +558,7 @@ int enqueue_step(wmar_gpt* g, int64_t B, const StepIO& io, hipStream_t st) {
     }
     if ((rc = p.embed())) return rc;
     if (p.small) {
-        // 1..8 rows: five streaming launches per layer, the residual stream updated in place (decode_small.h)
+        // 1..12 rows: five streaming launches per layer, the residual stream updated in place (decode_small.h)
         for (int l = 0; l < g->L; ++l) {
             if ((rc = p.qkv_small(l))) return rc;
             if ((rc = p.attn(l))) return rc;
@@ -727,7 +727,7 @@ int wmar_gpt_create(const wmar_gpt_config* cfg, const char* const* names, const 
         TRY(copy_vec(g, &w.bfc2, f2b, D, st));
     }
     // small-batch path (decode_small.h): the weights once more in the checkpoint's row-major layout (LayerNorm not folded), 5.5 GB at
-    // 48 layers x 1536.  Shapes: n_embd = two K segments of 768, head_dim 64.  WMAR_NO_SMALL=1 at creation keeps 1..8 rows on the
+    // 48 layers x 1536.  Shapes: n_embd = two K segments of 768, head_dim 64.  WMAR_NO_SMALL=1 at creation keeps 1..12 rows on the
     // matrix-core plan (A/B, tests).
     if (rc == WMAR_OK && D == 2 * SG_SEG && hd == 64 && !getenv("WMAR_NO_SMALL")) {
         g->sw.resize(L);
