@@ -11,7 +11,7 @@ for role, kn in K.items():
         f = glob.glob(f"gpurun_out/pmc/{role}_{ctr}/*/*counter_collection.csv")[0]
         rows = list(csv.DictReader(open(f)))
         keep = [r for r in rows if re.search(r"(^|::)" + kn + r"[<(]", r["Kernel_Name"]) and r["Counter_Name"] == ctr][-48:]
-        with open(f"gpurun_out/pmc_out/r05_pmc_{ctr}_{role}.csv", "w", newline="") as o:
+        with open(f"gpurun_out/pmc_out/r06_pmc_{ctr}_{role}.csv", "w", newline="") as o:
             w = csv.DictWriter(o, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(keep)
 PY
 rm -rf gpurun_out/pmc

@@ -8,7 +8,7 @@ ALG = {"attn": ("k_attn_decode", 2.0 * 64 * 1536 * 4 * 128 + 64 * 3 * 1536 * 4 *
        "fc2": ("k_gemm", 4 * 1536 * 1536 * 4 + 64 * 6144 * 4 + (16 * 6 + 32 * 5) / 48 * 64 * 1536 * 4, "FC2 weights + the hidden activation (read once) + 5.33 split-K slabs written"),
        # round 4: k_bx_xr = projection + XCD-local reduction + residual fold + LN2 statistics in one launch
        "proj": ("k_bx_xr", 1536 * 1536 * 4 + 64 * 1536 * 6 + 4 * 64 * 1536 * 4 + 2 * 64 * 1536 * 4, "proj weights + the attention output as bf16 pieces (read once) + 4 split-K slabs written (read back inside the XCD: L2) + the residual stream read and written")}
-ROUND = 5
+ROUND = 6
 for role in sys.argv[1:]:
     kname, alg, what = ALG[role]
     vals = {}
